@@ -1,0 +1,205 @@
+/*
+ * vllm_amd.h -- C ABI of libvllm_amd.so: the MI355X (gfx950) quantized decode
+ * hot path of vLLM, hand-written HIP.
+ *
+ * Every entry point replaces ONE reference operator (cited per function,
+ * paths relative to the ROCm/vllm tree).  Conventions, identical to the
+ * reference's op contract:
+ *   - all pointers are DEVICE pointers owned by the caller (including the
+ *     temporaries tmp_out/exp_sums/max_logits and the pre-zeroed dynamic
+ *     scale); nothing is allocated, freed or synchronised inside a call, so
+ *     every call is HIP-graph capturable;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) of the CURRENT device;
+ *   - strides are in ELEMENTS of the tensor they describe;
+ *   - the return value is 0 on success or a negative VLLM_AMD_E* code; the
+ *     message (the text the reference would put in its TORCH_CHECK) is
+ *     returned by vllm_amd_last_error() for the calling thread;
+ *   - calls are not re-entrant per stream but are thread-safe across threads.
+ */
+#ifndef VLLM_AMD_H_
+#define VLLM_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* activation / query / output element types (reference: VLLM_DISPATCH_FLOATING_TYPES,
+ * csrc/dispatch_utils.h) */
+enum { VLLM_AMD_F32 = 0, VLLM_AMD_F16 = 1, VLLM_AMD_BF16 = 2 };
+/* KV-cache storage (reference: Fp8KVCacheDataType, csrc/attention/dtype_fp8.cuh:14-18;
+ * strings "auto" | "fp8" | "fp8_e4m3", csrc/quantization/fp8/amd/quant_utils.cuh:641-667).
+ * gfx950 fp8 is OCP e4m3fn (max 448). */
+enum { VLLM_AMD_KV_AUTO = 0, VLLM_AMD_KV_FP8_E4M3 = 1 };
+
+enum {
+  VLLM_AMD_OK = 0,
+  VLLM_AMD_EINVAL = -1,      /* bad argument (null pointer, negative size ...) */
+  VLLM_AMD_EUNSUPPORTED = -2,/* "Unsupported head size / block size / dtype ..." */
+  VLLM_AMD_EHIP = -3         /* a HIP runtime call failed */
+};
+
+const char* vllm_amd_last_error(void);
+/* 10000*major + 100*minor + patch */
+int vllm_amd_version(void);
+
+/* ------------------------------------------------------------------------- */
+/* Paged attention (decode: one query token per sequence).                    */
+/* key_cache  [num_blocks, num_kv_heads, head_size/x, block_size, x]          */
+/* value_cache[num_blocks, num_kv_heads, head_size, block_size]               */
+/* x = 16 / sizeof(cache element); fp8 caches are bytes, x = 16.              */
+/* ------------------------------------------------------------------------- */
+
+/* Replaces torch.ops._C.paged_attention_v1
+ *   schema  csrc/torch_bindings.cpp:45-55, launcher csrc/attention/paged_attention_v1.cu:46-182,
+ *   kernel  csrc/attention/attention_kernels.cuh:85-522, python vllm/_custom_ops.py:39-65.
+ * out/query: [num_seqs, num_heads, head_size] (query row stride q_stride, out contiguous).
+ * k_scale/v_scale: device float[1].  alibi_slopes: device float[num_heads] or NULL.
+ * blocksparse_* as in the reference (vert_stride <= 1 disables). */
+int vllm_amd_paged_attention_v1(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int* block_tables, const int* seq_lens, int max_num_blocks_per_seq,
+    int block_size, int max_seq_len, const float* alibi_slopes, int dtype,
+    int kv_dtype, const float* k_scale, const float* v_scale, int64_t q_stride,
+    int64_t kv_block_stride, int64_t kv_head_stride, int tp_rank,
+    int blocksparse_local_blocks, int blocksparse_vert_stride,
+    int blocksparse_block_size, int blocksparse_head_sliding_step, void* stream);
+
+/* Replaces torch.ops._C.paged_attention_v2
+ *   schema csrc/torch_bindings.cpp:58-69, launcher csrc/attention/paged_attention_v2.cu:46-192,
+ *   kernels csrc/attention/attention_kernels.cuh:529-664, python vllm/_custom_ops.py:68-97.
+ * exp_sums/max_logits: float [num_seqs, num_heads, max_num_partitions];
+ * tmp_out: dtype [num_seqs, num_heads, max_num_partitions, head_size];
+ * partition = 512 tokens (vllm/attention/ops/paged_attn.py:16). */
+int vllm_amd_paged_attention_v2(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int* block_tables, const int* seq_lens, int max_num_blocks_per_seq,
+    int block_size, int max_seq_len, int max_num_partitions,
+    const float* alibi_slopes, int dtype, int kv_dtype, const float* k_scale,
+    const float* v_scale, int64_t q_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride, int tp_rank, int blocksparse_local_blocks,
+    int blocksparse_vert_stride, int blocksparse_block_size,
+    int blocksparse_head_sliding_step, void* stream);
+
+/* Replaces torch.ops._rocm_C.paged_attention
+ *   schema csrc/rocm/torch_bindings.cpp:42-56, entry csrc/rocm/attention.cu:3494-3539,
+ *   launcher :3073-3228, python vllm/_custom_ops.py:100-126.
+ * partition = 256 tokens; num_seqs = block_tables rows; query_start_loc
+ * (int[num_seqs+1] or NULL) selects the query/out row of each sequence and
+ * sequences whose query length != 1 are skipped; fp8_out_scale (float[1] or
+ * NULL): when given, `out` is e4m3 bytes = out / *fp8_out_scale. */
+int vllm_amd_paged_attention_rocm(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int* block_tables, const int* context_lens, const int* query_start_loc,
+    int max_num_blocks_per_seq, int block_size, int max_context_len,
+    int max_num_partitions, const float* alibi_slopes, int dtype, int kv_dtype,
+    const float* k_scale, const float* v_scale, const float* fp8_out_scale,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* KV-cache writes                                                            */
+/* ------------------------------------------------------------------------- */
+
+/* Replaces torch.ops._C_cache_ops.reshape_and_cache
+ *   schema csrc/torch_bindings.cpp:676-682, csrc/cache_kernels.cu:210-262, 369-395,
+ *   python vllm/_custom_ops.py:1617-1629.  slot_mapping: int64[num_tokens], <0 = skip. */
+int vllm_amd_reshape_and_cache(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+    int block_size, int x, int64_t key_stride, int64_t value_stride, int dtype,
+    int kv_dtype, const float* k_scale, const float* v_scale, void* stream);
+
+/* Replaces torch.ops._C_cache_ops.reshape_and_cache_flash
+ *   schema csrc/torch_bindings.cpp:685-693, csrc/cache_kernels.cu:264-306, 412-450,
+ *   python vllm/_custom_ops.py:1632-1645.
+ * caches [num_blocks, block_size, num_heads, head_size] addressed through
+ * block_stride/page_stride/head_stride (NHD or permuted HND views). */
+int vllm_amd_reshape_and_cache_flash(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+    int block_size, int64_t key_stride, int64_t value_stride,
+    int64_t block_stride, int64_t page_stride, int64_t head_stride, int dtype,
+    int kv_dtype, const float* k_scale, const float* v_scale, void* stream);
+
+/* Replaces torch.ops._C_cache_ops.convert_fp8
+ *   schema csrc/torch_bindings.cpp:705-708, csrc/cache_kernels.cu:505-576,
+ *   python vllm/_custom_ops.py:1677-1681.
+ * to_fp8 != 0: src (dtype) -> dst (e4m3 bytes), x / scale; else dst (dtype) =
+ * float(src byte) * scale.  n = number of elements. */
+int vllm_amd_convert_fp8(void* dst, const void* src, int64_t n, float scale,
+                         int dtype, int to_fp8, void* stream);
+
+/* Replaces torch.ops._C_cache_ops.copy_blocks for ONE layer
+ *   csrc/cache_kernels.cu:71-170, python vllm/_custom_ops.py:1661-1664.
+ * block_mapping: device int64 [num_pairs, 2] (src, dst); block_bytes = bytes of
+ * one cache block. */
+int vllm_amd_copy_blocks(void* key_cache, void* value_cache,
+                         const int64_t* block_mapping, int num_pairs,
+                         int64_t block_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* fp8 (e4m3fn) quantisation, input [num_tokens, hidden] contiguous           */
+/* ------------------------------------------------------------------------- */
+
+/* Replaces torch.ops._C.static_scaled_fp8_quant
+ *   schema csrc/torch_bindings.cpp:575-578, csrc/quantization/fp8/common.cu:14-26, 87-110. */
+int vllm_amd_static_scaled_fp8_quant(void* out, const void* input,
+                                     const float* scale, int64_t num_tokens,
+                                     int hidden_size, int dtype, void* stream);
+/* Replaces torch.ops._C.dynamic_scaled_fp8_quant
+ *   schema csrc/torch_bindings.cpp:581-585, common.cu:112-139, common.cuh:64-97.
+ * *scale must be <= 0 on entry (the python wrapper zeroes it, _custom_ops.py:1297). */
+int vllm_amd_dynamic_scaled_fp8_quant(void* out, const void* input, float* scale,
+                                      int64_t num_tokens, int hidden_size,
+                                      int dtype, void* stream);
+/* Replaces torch.ops._C.dynamic_per_token_scaled_fp8_quant
+ *   schema csrc/torch_bindings.cpp:588-593, common.cu:28-83, 141-171.
+ * scales: float[num_tokens] out; scale_ub: float[1] or NULL. */
+int vllm_amd_dynamic_per_token_scaled_fp8_quant(void* out, const void* input,
+                                                float* scales,
+                                                const float* scale_ub,
+                                                int64_t num_tokens,
+                                                int hidden_size, int dtype,
+                                                void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* w8a8 fp8 GEMMs                                                             */
+/* ------------------------------------------------------------------------- */
+
+/* Replaces torch.ops._C.cutlass_scaled_mm (fp8 x fp8 case) and the
+ * torch._scaled_mm call of torch_per_token_w8a8_scaled_mm
+ *   schema csrc/torch_bindings.cpp:422-427, python vllm/_custom_ops.py:697-742,
+ *   vllm/model_executor/layers/quantization/utils/w8a8_utils.py:199-226.
+ * out[M,N] = ((a_scales (.) a) . (b_scales (.) b)).to(out_dtype) (+ bias)
+ * a: e4m3 [M,K] row-major (row stride lda); b: e4m3 [K,N] COLUMN-major, i.e.
+ * element (k,n) at b[n*ldb + k] (the reference passes weight.t());
+ * a_scales: float[1] or [M]; b_scales: float[1] or [N]; bias: out_dtype[N] or NULL;
+ * out row stride ldc.  K % 16 == 0. */
+int vllm_amd_scaled_mm(void* out, const void* a, const void* b,
+                       const float* a_scales, const float* b_scales,
+                       const void* bias, int M, int N, int K, int64_t lda,
+                       int64_t ldb, int64_t ldc, int a_scale_numel,
+                       int b_scale_numel, int out_dtype, void* stream);
+
+/* Replaces torch.ops._rocm_C.wvSplitKQ
+ *   schema csrc/rocm/torch_bindings.cpp:34-37, csrc/rocm/skinny_gemms.cu:1649-1714,
+ *   python vllm/_custom_ops.py:1501-1508.
+ * out_c[N_in, M_in] = (in_b[N_in,K] . in_a[M_in,K]^T) * scale_a * scale_b,
+ * per-tensor scales (float[1] each), N_in <= 4, K % 16 == 0. */
+int vllm_amd_wvSplitKQ(const void* in_a, const void* in_b, void* out_c,
+                       const float* scale_a, const float* scale_b, int M_in,
+                       int K_in, int N_in, int out_dtype, int cu_count,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLLM_AMD_H_ */

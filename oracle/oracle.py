@@ -1,0 +1,251 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-end of oracle/liboracle.so.
+
+Mirrors the argument lists of the reference's `vllm/_custom_ops.py` wrappers
+(file:line cited per function) but runs the plain-C restatement in
+`oracle/oracle.c` on CPU tensors.  Only tests/, `__graft_entry__.smoke()` and
+`bench.py`'s cpu_baseline leg import this module; nothing under `vllm_amd/`
+does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_REF_PATH = os.path.join(_HERE, "_ref", "librefcpu.so")
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} missing: run `make -C oracle` (or __graft_entry__.build())")
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.oracle_fp8_e4m3_to_f32.restype = C.c_float
+        _lib.oracle_fp8_e4m3_to_f32.argtypes = [C.c_uint8]
+        _lib.oracle_f32_to_fp8_e4m3.restype = C.c_uint8
+        _lib.oracle_f32_to_fp8_e4m3.argtypes = [C.c_float]
+    return _lib
+
+
+_ref_loaded = False
+
+
+def load_ref() -> bool:
+    """Load oracle/_ref/librefcpu.so (the reference's own CPU kernels compiled
+    by oracle/Makefile) into torch.ops.refcpu.  Returns False if absent."""
+    global _ref_loaded
+    if _ref_loaded:
+        return True
+    if not os.path.exists(_REF_PATH):
+        return False
+    torch.ops.load_library(_REF_PATH)
+    _ref_loaded = True
+    return True
+
+
+DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def _kv(kv_cache_dtype: str) -> int:
+    if kv_cache_dtype == "auto":
+        return 0
+    if kv_cache_dtype in ("fp8", "fp8_e4m3"):
+        return 1
+    raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.device.type == "cpu"
+    return C.c_void_p(t.data_ptr())
+
+
+def _f(x) -> C.c_float:
+    return C.c_float(float(x))
+
+
+def _i64(x) -> C.c_int64:
+    return C.c_int64(int(x))
+
+
+# ----------------------------------------------------------------------------
+def fp8_decode_table() -> torch.Tensor:
+    l = lib()
+    return torch.tensor([l.oracle_fp8_e4m3_to_f32(i) for i in range(256)],
+                        dtype=torch.float32)
+
+
+def fp8_encode(x: torch.Tensor) -> torch.Tensor:
+    """float32 tensor -> uint8 e4m3fn codes (RNE, saturating)."""
+    x = x.float().contiguous()
+    out = torch.empty(x.shape, dtype=torch.uint8)
+    l = lib()
+    l.oracle_convert_fp8(_p(out), _p(x), _i64(x.numel()), _f(1.0), 0, 1)
+    return out
+
+
+# vllm/_custom_ops.py:1617-1629
+def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping,
+                      kv_cache_dtype, k_scale, v_scale) -> None:
+    num_tokens = slot_mapping.shape[0]
+    _, num_heads, head_size = key.shape
+    block_size, x = key_cache.shape[3], key_cache.shape[4]
+    lib().oracle_reshape_and_cache(
+        _p(key), _p(value), _p(key_cache), _p(value_cache), _p(slot_mapping),
+        num_tokens, num_heads, head_size, block_size, x, _i64(key.stride(0)),
+        _i64(value.stride(0)), DT[key.dtype], _kv(kv_cache_dtype),
+        _f(k_scale), _f(v_scale))
+
+
+# vllm/_custom_ops.py:1632-1645
+def reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping,
+                            kv_cache_dtype, k_scale, v_scale) -> None:
+    num_tokens = slot_mapping.shape[0]
+    _, num_heads, head_size = key.shape
+    block_size = key_cache.shape[1]
+    lib().oracle_reshape_and_cache_flash(
+        _p(key), _p(value), _p(key_cache), _p(value_cache), _p(slot_mapping),
+        num_tokens, num_heads, head_size, block_size, _i64(key.stride(0)),
+        _i64(value.stride(0)), _i64(key_cache.stride(0)),
+        _i64(key_cache.stride(1)), _i64(key_cache.stride(2)), DT[key.dtype],
+        _kv(kv_cache_dtype), _f(k_scale), _f(v_scale))
+
+
+# vllm/_custom_ops.py:1677-1681
+def convert_fp8(output, input, scale: float = 1.0, kv_dtype: str = "fp8") -> None:
+    assert input.is_contiguous() and output.is_contiguous()
+    if output.dtype == torch.uint8:
+        lib().oracle_convert_fp8(_p(output), _p(input), _i64(input.numel()),
+                                 _f(scale), DT[input.dtype], 1)
+    else:
+        lib().oracle_convert_fp8(_p(output), _p(input), _i64(input.numel()),
+                                 _f(scale), DT[output.dtype], 0)
+
+
+# vllm/_custom_ops.py:1244-1304
+def scaled_fp8_quant(input, scale=None, num_token_padding=None, scale_ub=None,
+                     use_per_token_if_dynamic=False):
+    assert input.ndim == 2
+    input = input.contiguous()
+    shape = input.shape
+    if num_token_padding:
+        shape = (max(num_token_padding, shape[0]), shape[1])
+    out = torch.zeros(shape, dtype=torch.uint8)
+    n = input.numel()
+    if scale is None:
+        if use_per_token_if_dynamic:
+            scale = torch.zeros((shape[0], 1), dtype=torch.float32)
+            lib().oracle_dynamic_per_token_scaled_fp8_quant(
+                _p(out), _p(input), _p(scale), _p(scale_ub),
+                _i64(input.shape[0]), input.shape[1], DT[input.dtype])
+        else:
+            scale = torch.zeros(1, dtype=torch.float32)
+            lib().oracle_dynamic_scaled_fp8_quant(_p(out), _p(input), _p(scale),
+                                                  _i64(n), DT[input.dtype])
+    else:
+        assert scale.numel() == 1
+        lib().oracle_static_scaled_fp8_quant(_p(out), _p(input),
+                                             _f(scale.item()), _i64(n),
+                                             DT[input.dtype])
+    return out, scale
+
+
+# vllm/_custom_ops.py:697-742  (a: [M,K] uint8 codes; b: [K,N] with stride(0)==1)
+def scaled_mm(a, b, scale_a, scale_b, out_dtype, bias=None):
+    M, K = a.shape
+    K2, N = b.shape
+    assert K == K2 and b.stride(0) == 1 and a.stride(1) == 1
+    out = torch.empty((M, N), dtype=out_dtype)
+    scale_a = scale_a.float().contiguous()
+    scale_b = scale_b.float().contiguous()
+    lib().oracle_scaled_mm(_p(out), _p(a), _p(b), _p(scale_a), _p(scale_b),
+                           _p(bias), M, N, K, _i64(a.stride(0)),
+                           _i64(b.stride(1)), scale_a.numel(), scale_b.numel(),
+                           DT[out_dtype])
+    return out
+
+
+def _attn_common(query, key_cache, value_cache, num_kv_heads, scale,
+                 block_tables, seq_lens, block_size, alibi_slopes,
+                 kv_cache_dtype, k_scale, v_scale):
+    num_seqs, num_heads, head_size = query.shape
+    return [
+        _p(query), _p(key_cache), _p(value_cache), num_seqs, num_heads,
+        head_size, num_kv_heads, _f(scale), _p(block_tables), _p(seq_lens),
+        block_tables.shape[1], block_size, _p(alibi_slopes), DT[query.dtype],
+        _kv(kv_cache_dtype), _f(k_scale), _f(v_scale), _i64(query.stride(0)),
+        _i64(key_cache.stride(0)), _i64(key_cache.stride(1))
+    ]
+
+
+# vllm/_custom_ops.py:39-65
+def paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale,
+                       block_tables, seq_lens, block_size, max_seq_len,
+                       alibi_slopes, kv_cache_dtype, k_scale, v_scale,
+                       tp_rank=0, blocksparse_local_blocks=0,
+                       blocksparse_vert_stride=0, blocksparse_block_size=64,
+                       blocksparse_head_sliding_step=0) -> None:
+    args = _attn_common(query, key_cache, value_cache, num_kv_heads, scale,
+                        block_tables, seq_lens, block_size, alibi_slopes,
+                        kv_cache_dtype, k_scale, v_scale)
+    lib().oracle_paged_attention_v1(
+        _p(out), *args, tp_rank, blocksparse_local_blocks,
+        blocksparse_vert_stride, blocksparse_block_size,
+        blocksparse_head_sliding_step)
+
+
+# vllm/_custom_ops.py:68-97
+def paged_attention_v2(out, exp_sum, max_logits, tmp_out, query, key_cache,
+                       value_cache, num_kv_heads, scale, block_tables, seq_lens,
+                       block_size, max_seq_len, alibi_slopes, kv_cache_dtype,
+                       k_scale, v_scale, tp_rank=0, blocksparse_local_blocks=0,
+                       blocksparse_vert_stride=0, blocksparse_block_size=64,
+                       blocksparse_head_sliding_step=0,
+                       partition_size=512) -> None:
+    args = _attn_common(query, key_cache, value_cache, num_kv_heads, scale,
+                        block_tables, seq_lens, block_size, alibi_slopes,
+                        kv_cache_dtype, k_scale, v_scale)
+    lib().oracle_paged_attention_v2(
+        _p(out), _p(exp_sum), _p(max_logits), _p(tmp_out), *args, tp_rank,
+        blocksparse_local_blocks, blocksparse_vert_stride,
+        blocksparse_block_size, blocksparse_head_sliding_step, partition_size,
+        exp_sum.shape[-1])
+
+
+# vllm/_custom_ops.py:100-126
+def paged_attention_rocm(out, exp_sum, max_logits, tmp_out, query, key_cache,
+                         value_cache, num_kv_heads, scale, block_tables,
+                         seq_lens, query_start_loc, block_size, max_seq_len,
+                         alibi_slopes, kv_cache_dtype, k_scale, v_scale,
+                         fp8_out_scale=None) -> None:
+    num_seqs = block_tables.shape[0]
+    _, num_heads, head_size = query.shape
+    lib().oracle_paged_attention_rocm(
+        _p(out), _p(exp_sum), _p(max_logits), _p(tmp_out), _p(query),
+        _p(key_cache), _p(value_cache), num_seqs, num_heads, head_size,
+        num_kv_heads, _f(scale), _p(block_tables), _p(seq_lens),
+        _p(query_start_loc), block_tables.shape[1], block_size,
+        _p(alibi_slopes), DT[query.dtype], _kv(kv_cache_dtype), _f(k_scale),
+        _f(v_scale), _i64(query.stride(0)), _i64(key_cache.stride(0)),
+        _i64(key_cache.stride(1)), exp_sum.shape[-1], _p(fp8_out_scale))
+
+
+def paged_attention_f64(query, key_cache, value_cache, num_kv_heads, scale,
+                        block_tables, seq_lens, block_size, alibi_slopes,
+                        kv_cache_dtype, k_scale, v_scale) -> torch.Tensor:
+    """fp64 ground truth (no intermediate rounding); bounds both sides' error."""
+    out = torch.empty(query.shape, dtype=torch.float64)
+    args = _attn_common(query, key_cache, value_cache, num_kv_heads, scale,
+                        block_tables, seq_lens, block_size, alibi_slopes,
+                        kv_cache_dtype, k_scale, v_scale)
+    lib().oracle_paged_attention_f64(_p(out), *args)
+    return out

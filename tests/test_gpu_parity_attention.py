@@ -1,0 +1,183 @@
+"""GPU parity: HIP paged attention (through torch.ops -> C ABI) vs the CPU oracle.
+
+Tolerances are the reference's own (tests/kernels/attention/test_attention.py:345-348):
+atol 1e-3 / rtol 1e-5 for 16/32-bit KV ("auto"), atol 1e-2 for fp8 KV -- we use
+a tighter 2e-3 for fp8 because both sides use the exact fp8 values.
+"""
+import pytest
+import torch
+
+from helpers import make_attn_case, to_dev
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"auto": dict(atol=1e-3, rtol=1e-5), "fp8": dict(atol=2e-3, rtol=1e-5)}
+
+
+def run_case(ops, oracle, c, version, partition=None, query_start_loc=None, fp8_out_scale=None):
+    q, kc, vc, bt, sl = c["q"], c["kc"], c["vc"], c["bt"], c["sl"]
+    S, H, D = q.shape
+    ks = torch.tensor([c["kv_scale"]], dtype=torch.float32)
+    vs = torch.tensor([c["kv_scale"]], dtype=torch.float32)
+    dq, dkc, dvc, dbt, dsl = (to_dev(t) for t in (q, kc, vc, bt, sl))
+    dsl_, dks, dvs = to_dev(c["slopes"]), to_dev(ks), to_dev(vs)
+    out_o = torch.zeros_like(q)
+    if version == "v1":
+        out = torch.full_like(dq, float("nan"))
+        ops.paged_attention_v1(out, dq, dkc, dvc, c["num_kv_heads"], c["scale"], dbt, dsl,
+                               c["block_size"], c["max_len"], dsl_, c["kv_cache_dtype"], dks, dvs)
+        oracle.paged_attention_v1(out_o, q, kc, vc, c["num_kv_heads"], c["scale"], bt, sl,
+                                  c["block_size"], c["max_len"], c["slopes"], c["kv_cache_dtype"],
+                                  c["kv_scale"], c["kv_scale"])
+    else:
+        PS = 512 if version == "v2" else 256
+        P = (c["max_len"] + PS - 1) // PS
+        es = torch.zeros((S, H, P), dtype=torch.float32)
+        ml = torch.zeros_like(es)
+        tmp = torch.zeros((S, H, P, D), dtype=q.dtype)
+        des, dml, dtmp = to_dev(es), to_dev(ml), to_dev(tmp)
+        out = torch.full_like(dq, float("nan"))
+        if version == "v2":
+            ops.paged_attention_v2(out, des, dml, dtmp, dq, dkc, dvc, c["num_kv_heads"], c["scale"],
+                                   dbt, dsl, c["block_size"], c["max_len"], dsl_,
+                                   c["kv_cache_dtype"], dks, dvs)
+            oracle.paged_attention_v2(out_o, es, ml, tmp, q, kc, vc, c["num_kv_heads"], c["scale"],
+                                      bt, sl, c["block_size"], c["max_len"], c["slopes"],
+                                      c["kv_cache_dtype"], c["kv_scale"], c["kv_scale"])
+        else:
+            ops.paged_attention_rocm(out, des, dml, dtmp, dq, dkc, dvc, c["num_kv_heads"],
+                                     c["scale"], dbt, dsl, None, c["block_size"], c["max_len"],
+                                     dsl_, c["kv_cache_dtype"], dks, dvs)
+            oracle.paged_attention_rocm(out_o, es, ml, tmp, q, kc, vc, c["num_kv_heads"],
+                                        c["scale"], bt, sl, None, c["block_size"], c["max_len"],
+                                        c["slopes"], c["kv_cache_dtype"], c["kv_scale"],
+                                        c["kv_scale"])
+    torch.cuda.synchronize()
+    got = out.cpu().float()
+    kind = "auto" if c["kv_cache_dtype"] == "auto" else "fp8"
+    torch.testing.assert_close(got, out_o.float(), **TOL[kind])
+    # and both must sit near the unrounded fp64 answer
+    f64 = oracle.paged_attention_f64(q, kc, vc, c["num_kv_heads"], c["scale"], bt, sl,
+                                     c["block_size"], c["slopes"], c["kv_cache_dtype"],
+                                     c["kv_scale"], c["kv_scale"])
+    assert (got.double() - f64).abs().max().item() < TOL[kind]["atol"]
+
+
+SEQ_LENS = [1, 15, 16, 17, 63, 64, 65, 300, 513, 1029]
+
+
+@pytest.mark.parametrize("version", ["v1", "v2", "rocm"])
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("heads", [(32, 8), (8, 1), (5, 5), (16, 1)])
+def test_mfma_path(ops, oracle, version, kv, dtype, heads):
+    H, KVH = heads
+    c = make_attn_case(len(SEQ_LENS), H, KVH, 128, 16, dtype, kv, SEQ_LENS, seed=H,
+                       kv_scale=1.0 if kv == "auto" else 0.5)
+    run_case(ops, oracle, c, version)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2", "rocm"])
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("hs_bs", [(64, 16), (128, 32), (64, 32)])
+def test_mfma_shapes(ops, oracle, version, kv, hs_bs):
+    hs, bs = hs_bs
+    c = make_attn_case(6, 8, 2, hs, bs, torch.bfloat16, kv, [1, 31, 32, 33, 600, 1100], seed=7,
+                       kv_scale=1.0 if kv == "auto" else 0.25, alibi=(hs == 64))
+    run_case(ops, oracle, c, version)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hs_bs", [(80, 16), (256, 8), (120, 32), (32, 16), (192, 16), (96, 8), (112, 16)])
+def test_generic_path(ops, oracle, version, kv, dtype, hs_bs):
+    hs, bs = hs_bs
+    c = make_attn_case(5, 8, 4, hs, bs, dtype, kv, [1, 7, 130, 515, 700], seed=3,
+                       kv_scale=1.0 if kv == "auto" else 0.5, alibi=(bs == 16))
+    run_case(ops, oracle, c, version)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2", "rocm"])
+def test_alibi_gqa(ops, oracle, version):
+    c = make_attn_case(4, 64, 8, 128, 16, torch.bfloat16, "fp8", [5, 100, 777, 2049], seed=11,
+                       kv_scale=0.5, alibi=True)
+    run_case(ops, oracle, c, version)
+
+
+def test_blocksparse_v1_v2(ops, oracle):
+    """block-sparse arguments of v1/v2 (attention_kernels.cuh:204-251, 380-388)."""
+    c = make_attn_case(3, 8, 2, 128, 16, torch.bfloat16, "auto", [200, 640, 1500], seed=5)
+    q, kc, vc, bt, sl = c["q"], c["kc"], c["vc"], c["bt"], c["sl"]
+    one = torch.ones(1)
+    args = dict(tp_rank=1, blocksparse_local_blocks=2, blocksparse_vert_stride=3,
+                blocksparse_block_size=64, blocksparse_head_sliding_step=1)
+    out_o = torch.zeros_like(q)
+    oracle.paged_attention_v1(out_o, q, kc, vc, 2, c["scale"], bt, sl, 16, c["max_len"], None,
+                              "auto", 1.0, 1.0, **args)
+    out = torch.empty_like(q, device="cuda")
+    ops.paged_attention_v1(out, q.cuda(), kc.cuda(), vc.cuda(), 2, c["scale"], bt.cuda(), sl.cuda(),
+                           16, c["max_len"], None, "auto", one.cuda(), one.cuda(), **args)
+    torch.testing.assert_close(out.cpu().float(), out_o.float(), atol=1e-3, rtol=1e-5)
+    P = (c["max_len"] + 511) // 512
+    S, H, D = q.shape
+    es = torch.zeros((S, H, P)); ml = torch.zeros_like(es); tmp = torch.zeros((S, H, P, D), dtype=q.dtype)
+    out2 = torch.empty_like(q, device="cuda")
+    ops.paged_attention_v2(out2, es.cuda(), ml.cuda(), tmp.cuda(), q.cuda(), kc.cuda(), vc.cuda(), 2,
+                           c["scale"], bt.cuda(), sl.cuda(), 16, c["max_len"], None, "auto",
+                           one.cuda(), one.cuda(), **args)
+    out_o2 = torch.zeros_like(q)
+    oracle.paged_attention_v2(out_o2, es, ml, tmp, q, kc, vc, 2, c["scale"], bt, sl, 16,
+                              c["max_len"], None, "auto", 1.0, 1.0, **args)
+    torch.testing.assert_close(out2.cpu().float(), out_o2.float(), atol=1e-3, rtol=1e-5)
+
+
+def test_rocm_query_start_loc_and_fp8_out(ops, oracle):
+    """query_start_loc skips non-decode sequences and addresses q/out by token
+    (csrc/rocm/attention.cu:296-299, 385-388, 1464-1467); fp8_out_scale -> e4m3 output
+    (:1460-1474)."""
+    lens = [40, 300, 700, 90]
+    c = make_attn_case(4, 16, 2, 128, 16, torch.bfloat16, "fp8", lens, seed=9, kv_scale=0.5)
+    # token rows: seq0 -> row 0, seq1 = prefill of 3 tokens (rows 1..3, skipped), seq2 -> 4, seq3 -> 5
+    qsl = torch.tensor([0, 1, 4, 5, 6], dtype=torch.int32)
+    g = torch.Generator().manual_seed(1)
+    q_tok = ((torch.rand((6, 16, 128), generator=g) * 2 - 1) * 128 ** -0.5).to(torch.bfloat16)
+    S, H, D, P = 4, 16, 128, (700 + 255) // 256
+    ks = torch.tensor([0.5])
+    for fp8_out in (None, torch.tensor([0.02])):
+        es = torch.zeros((S, H, P)); ml = torch.zeros_like(es); tmp = torch.zeros((S, H, P, D), dtype=torch.bfloat16)
+        if fp8_out is None:
+            out_o = torch.full((6, H, D), 7.0, dtype=torch.bfloat16)
+            out = out_o.clone().cuda()
+        else:
+            out_o = torch.full((6, H, D), 9, dtype=torch.uint8)
+            out = out_o.clone().cuda()
+        oracle.paged_attention_rocm(out_o, es, ml, tmp, q_tok, c["kc"], c["vc"], 2, c["scale"],
+                                    c["bt"], c["sl"], qsl, 16, 700, None, "fp8", 0.5, 0.5, fp8_out)
+        ops.paged_attention_rocm(out, es.cuda(), ml.cuda(), tmp.cuda(), q_tok.cuda(), c["kc"].cuda(),
+                                 c["vc"].cuda(), 2, c["scale"], c["bt"].cuda(), c["sl"].cuda(),
+                                 qsl.cuda(), 16, 700, None, "fp8", ks.cuda(), ks.cuda(),
+                                 None if fp8_out is None else fp8_out.cuda())
+        got = out.cpu()
+        if fp8_out is None:
+            torch.testing.assert_close(got.float(), out_o.float(), atol=2e-3, rtol=1e-5)
+            assert (got[1:4] == 7.0).all()  # skipped rows untouched
+        else:
+            a = got.view(torch.float8_e4m3fn).float(); b = out_o.view(torch.float8_e4m3fn).float()
+            assert (got[1:4] == 9).all()
+            # one e4m3 ulp at most (the accumulators differ by ~1e-4 before rounding)
+            assert ((a - b).abs() <= 0.125 * b.abs().clamp(min=2 ** -6) + 1e-6).all()
+            assert (a != b).float().mean().item() < 0.05
+
+
+def test_unsupported_raises(ops):
+    q = torch.zeros((1, 8, 100), dtype=torch.bfloat16, device="cuda")
+    kc = torch.zeros((4, 8, 100 // 4, 16, 4), dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros((4, 8, 100, 16), dtype=torch.bfloat16, device="cuda")
+    bt = torch.zeros((1, 1), dtype=torch.int32, device="cuda")
+    sl = torch.ones(1, dtype=torch.int32, device="cuda")
+    one = torch.ones(1, device="cuda")
+    with pytest.raises(RuntimeError, match="Unsupported head size"):
+        ops.paged_attention_v1(torch.empty_like(q), q, kc, vc, 8, 1.0, bt, sl, 16, 1, None, "auto", one, one)
+    with pytest.raises(RuntimeError, match="Unsupported data type of kv cache"):
+        ops.paged_attention_v1(torch.empty_like(q), q, kc, vc, 8, 1.0, bt, sl, 16, 1, None, "fp8_e5m2", one, one)

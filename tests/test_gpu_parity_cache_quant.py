@@ -1,0 +1,193 @@
+"""GPU parity, bit-exact: KV-cache writes, convert_fp8, copy_blocks and the three
+fp8 quantisation modes vs the CPU oracle.  Shapes follow the reference's
+tests/kernels/attention/test_cache.py:121-350 and
+tests/kernels/quantization/test_fp8_quant.py:14-117."""
+import pytest
+import torch
+
+from helpers import x_of
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16, torch.float32]
+
+
+def _kv_inputs(T, H, D, dtype, seed, strided):
+    g = torch.Generator().manual_seed(seed)
+    if strided:  # key/value as slices of a fused qkv tensor: stride(0) != H*D
+        qkv = torch.randn((T, 3, H, D), generator=g).to(dtype)
+        return qkv[:, 1], qkv[:, 2]
+    return torch.randn((T, H, D), generator=g).to(dtype), torch.randn((T, H, D), generator=g).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("D", [64, 80, 120, 128, 256])
+@pytest.mark.parametrize("BS", [8, 16, 32])
+def test_reshape_and_cache(ops, oracle, dtype, kv, D, BS):
+    T, H, NB = 42, 8, 64
+    key, value = _kv_inputs(T, H, D, dtype, D + BS, strided=(D == 128))
+    x = x_of(dtype, kv)
+    cdt = dtype if kv == "auto" else torch.uint8
+    g = torch.Generator().manual_seed(5)
+    slots = torch.randperm(NB * BS, generator=g)[:T].to(torch.int64)
+    slots[3] = -1
+    slots[17] = -1
+    ks = (key.float().abs().max() / 64.0).item() if kv != "auto" else 1.0
+    vs = (value.float().abs().max() / 64.0).item() if kv != "auto" else 1.0
+    kc0 = torch.zeros((NB, H, D // x, BS, x), dtype=cdt)
+    vc0 = torch.zeros((NB, H, D, BS), dtype=cdt)
+    kc_o, vc_o = kc0.clone(), vc0.clone()
+    oracle.reshape_and_cache(key, value, kc_o, vc_o, slots, kv, ks, vs)
+    kc_d, vc_d = kc0.cuda(), vc0.cuda()
+    ops.reshape_and_cache(key.cuda(), value.cuda(), kc_d, vc_d, slots.cuda(), kv,
+                          torch.tensor([ks], device="cuda"), torch.tensor([vs], device="cuda"))
+    assert torch.equal(kc_d.cpu().view(torch.uint8), kc_o.view(torch.uint8))
+    assert torch.equal(vc_d.cpu().view(torch.uint8), vc_o.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("layout", ["NHD", "HND"])
+@pytest.mark.parametrize("D", [64, 120, 128])
+def test_reshape_and_cache_flash(ops, oracle, dtype, kv, layout, D):
+    T, H, NB, BS = 50, 4, 40, 16
+    key, value = _kv_inputs(T + 6, H, D, dtype, D, strided=False)   # key longer than slot_mapping
+    cdt = dtype if kv == "auto" else torch.uint8
+    g = torch.Generator().manual_seed(6)
+    slots = torch.randperm(NB * BS, generator=g)[:T].to(torch.int64)
+    slots[0] = -1
+    ks, vs = (0.37, 0.21) if kv != "auto" else (1.0, 1.0)
+    if layout == "NHD":
+        mk = lambda: torch.zeros((NB, BS, H, D), dtype=cdt)
+        view = lambda t: t
+    else:
+        mk = lambda: torch.zeros((NB, H, BS, D), dtype=cdt)
+        view = lambda t: t.permute(0, 2, 1, 3)
+    kc_o, vc_o = mk(), mk()
+    oracle.reshape_and_cache_flash(key, value, view(kc_o), view(vc_o), slots, kv, ks, vs)
+    kc_d, vc_d = mk().cuda(), mk().cuda()
+    ops.reshape_and_cache_flash(key.cuda(), value.cuda(), view(kc_d), view(vc_d), slots.cuda(), kv,
+                                torch.tensor([ks], device="cuda"), torch.tensor([vs], device="cuda"))
+    assert torch.equal(kc_d.cpu().view(torch.uint8), kc_o.view(torch.uint8))
+    assert torch.equal(vc_d.cpu().view(torch.uint8), vc_o.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_convert_fp8_roundtrip_and_exhaustive(ops, oracle, dtype):
+    # every e4m3 code decodes exactly like the oracle's table
+    codes = torch.arange(256, dtype=torch.uint8).repeat(4)
+    dec = torch.empty(codes.shape, dtype=dtype, device="cuda")
+    ops.convert_fp8(dec, codes.cuda(), 1.0, "fp8")
+    tab = oracle.fp8_decode_table().repeat(4).to(dtype)
+    got = dec.cpu()
+    nan = tab.float().isnan()
+    assert torch.equal(got[~nan].view(torch.int16 if dtype != torch.float32 else torch.int32),
+                       tab[~nan].view(torch.int16 if dtype != torch.float32 else torch.int32))
+    assert got[nan].float().isnan().all()
+    # encode: dense sweep incl. ties, subnormals, saturation
+    g = torch.Generator().manual_seed(0)
+    t = oracle.fp8_decode_table()
+    fin = t[~t.isnan()].sort().values
+    mids = (fin[:-1] + fin[1:]) / 2
+    x = torch.cat([torch.randn(50000, generator=g) * 100, torch.randn(50000, generator=g) * 0.02,
+                   torch.linspace(-500, 500, 40001), fin, mids, mids * (1 + 2 ** -10),
+                   mids * (1 - 2 ** -10), torch.tensor([0.0, -0.0, 1e-30, -1e-30, 3e38, -3e38])]).to(dtype)
+    for scale in (1.0, 0.37):
+        out_o = torch.empty(x.shape, dtype=torch.uint8)
+        oracle.convert_fp8(out_o, x, scale, "fp8")
+        out = torch.empty(x.shape, dtype=torch.uint8, device="cuda")
+        ops.convert_fp8(out, x.cuda(), scale, "fp8")
+        assert torch.equal(out.cpu(), out_o)
+
+
+def test_fp8_nan_inf_encoding(ops, oracle):
+    x = torch.tensor([float("nan"), float("inf"), float("-inf"), -float("nan")], dtype=torch.float32)
+    out = torch.empty(4, dtype=torch.uint8, device="cuda")
+    ops.convert_fp8(out, x.cuda(), 1.0, "fp8")
+    got = out.cpu()
+    out_o = torch.empty(4, dtype=torch.uint8)
+    oracle.convert_fp8(out_o, x, 1.0, "fp8")
+    # NaN/Inf bypass the clamp (amd_hip_fp8.h:561-575) and become e4m3 NaN (no inf in e4m3fn)
+    assert ((got & 0x7f) == 0x7f).all(), got
+    assert torch.equal(got & 0x7f, out_o & 0x7f)
+
+
+def test_copy_blocks(ops):
+    NB, L = 32, 3
+    g = torch.Generator().manual_seed(2)
+    kcs = [torch.randn((NB, 8, 16, 16, 8), generator=g).to(torch.bfloat16) for _ in range(L)]
+    vcs = [torch.randn((NB, 8, 128, 16), generator=g).to(torch.bfloat16) for _ in range(L)]
+    mapping = torch.tensor([[0, 5], [0, 9], [3, 30], [7, 1]], dtype=torch.int64)
+    dk, dv = [t.cuda() for t in kcs], [t.cuda() for t in vcs]
+    ops.copy_blocks(dk, dv, mapping.cuda())
+    for l in range(L):
+        for s, d in mapping.tolist():
+            kcs[l][d] = kcs[l][s]
+            vcs[l][d] = vcs[l][s]
+        assert torch.equal(dk[l].cpu(), kcs[l]) and torch.equal(dv[l].cpu(), vcs[l])
+
+
+def test_swap_blocks(ops):
+    src = torch.randn((8, 1024), device="cuda")
+    dst = torch.zeros((8, 1024))
+    ops.swap_blocks(src, dst, torch.tensor([[1, 2], [3, 0]], dtype=torch.int64))
+    torch.cuda.synchronize()
+    assert torch.equal(dst[2], src[1].cpu()) and torch.equal(dst[0], src[3].cpu())
+    with pytest.raises(RuntimeError, match="block_mapping must be on CPU"):
+        ops.swap_blocks(src, dst, torch.tensor([[1, 2]], dtype=torch.int64, device="cuda"))
+
+
+HIDDEN = [1, 2, 3, 4, 16, 67, 768, 2048, 5120, 5137, 8192, 8193, 1024, 1025, 1026, 1031, 1032, 14336]
+TOKENS = [1, 7, 83, 256]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hidden", HIDDEN)
+@pytest.mark.parametrize("tokens", [1, 83])
+@pytest.mark.parametrize("ub", [False, True])
+def test_dynamic_per_token_fp8_quant(ops, oracle, dtype, hidden, tokens, ub):
+    g = torch.Generator().manual_seed(hidden * 7 + tokens)
+    x = (torch.rand((tokens, hidden), generator=g) * 1000 + 1e-6).to(dtype)
+    x[0, 0] = 0 if hidden > 1 else x[0, 0]
+    scale_ub = torch.tensor([x.float().abs().mean().item()], dtype=torch.float32) if ub else None
+    q_o, s_o = oracle.scaled_fp8_quant(x, scale_ub=scale_ub, use_per_token_if_dynamic=True)
+    q, s = ops.scaled_fp8_quant(x.cuda(), scale_ub=None if scale_ub is None else scale_ub.cuda(),
+                                use_per_token_if_dynamic=True)
+    assert q.dtype == torch.float8_e4m3fn and s.shape == (tokens, 1)
+    assert torch.equal(s.cpu().view(torch.int32), s_o.view(torch.int32))
+    assert torch.equal(q.cpu().view(torch.uint8), q_o)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hidden", [1, 17, 1024, 1031, 5137, 8193])
+@pytest.mark.parametrize("tokens", TOKENS)
+def test_dynamic_per_tensor_and_static_fp8_quant(ops, oracle, dtype, hidden, tokens):
+    g = torch.Generator().manual_seed(hidden + tokens)
+    x = (torch.randn((tokens, hidden), generator=g) * 30).to(dtype)
+    q_o, s_o = oracle.scaled_fp8_quant(x)
+    q, s = ops.scaled_fp8_quant(x.cuda())
+    assert torch.equal(s.cpu().view(torch.int32), s_o.view(torch.int32))
+    assert torch.equal(q.cpu().view(torch.uint8), q_o)
+    st = torch.tensor([0.0123], dtype=torch.float32)
+    q_o2, _ = oracle.scaled_fp8_quant(x, st)
+    q2, _ = ops.scaled_fp8_quant(x.cuda(), st.cuda())
+    assert torch.equal(q2.cpu().view(torch.uint8), q_o2)
+
+
+def test_fp8_quant_padding_and_output_arg(ops, oracle):
+    x = torch.randn((5, 64)).to(torch.bfloat16)
+    q, s = ops.scaled_fp8_quant(x.cuda(), num_token_padding=17, use_per_token_if_dynamic=True)
+    assert q.shape == (17, 64) and s.shape == (17, 1)
+    q_o, s_o = oracle.scaled_fp8_quant(x, use_per_token_if_dynamic=True)
+    assert torch.equal(q[:5].cpu().view(torch.uint8), q_o)
+    out = torch.empty((5, 64), dtype=torch.float8_e4m3fn, device="cuda")
+    q2, _ = ops.scaled_fp8_quant(x.cuda(), use_per_token_if_dynamic=True, output=out)
+    assert q2.data_ptr() == out.data_ptr()
+
+
+def test_fp8_quant_large_int64_index(ops):
+    """int64 indexing regression of the reference (test_fp8_quant.py:98-117)."""
+    x = torch.full((2 ** 31 // 8192 + 2, 8192), 1.0, dtype=torch.bfloat16, device="cuda")
+    q, s = ops.scaled_fp8_quant(x, torch.tensor([1.0], device="cuda"))
+    assert (q[-1].view(torch.uint8) == 0x38).all() and (q[0].view(torch.uint8) == 0x38).all()

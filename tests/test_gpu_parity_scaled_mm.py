@@ -1,0 +1,86 @@
+"""GPU parity: fp8 w8a8 scaled GEMM vs the CPU oracle (fp64-accumulated, scales
+then cast, bias in the output dtype: triton_scaled_mm.py:87-110).
+
+Stated tolerance (tighter than the reference's rtol=atol=1e-1 of
+test_triton_scaled_mm.py:110-114): products are exact and accumulation is fp32,
+so the only differences are fp32 summation order (<= K * 2^-24 relative to
+sum|a*b|) and one output rounding: rtol 1.6e-2 (2 bf16 ulp), atol 1e-2*|sa*sb| scale.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make(M, N, K, seed, per_token, per_channel, out_dtype, bias):
+    g = torch.Generator().manual_seed(seed)
+    a = (torch.randn((M, K), generator=g)).clamp(-448, 448).to(torch.float8_e4m3fn)
+    w = (torch.randn((N, K), generator=g)).clamp(-448, 448).to(torch.float8_e4m3fn)
+    sa = (torch.rand((M, 1) if per_token else (1, 1), generator=g) + 0.5) * 0.02
+    sb = (torch.rand((N, 1) if per_channel else (1, 1), generator=g) + 0.5) * 0.02
+    b = (torch.randn(N, generator=g) * 0.5).to(out_dtype) if bias else None
+    return a, w, sa.float(), sb.float(), b
+
+
+def check(ops, oracle, M, N, K, per_token, per_channel, out_dtype, bias, seed=0):
+    a, w, sa, sb, b = make(M, N, K, seed, per_token, per_channel, out_dtype, bias)
+    ref = oracle.scaled_mm(a.view(torch.uint8), w.view(torch.uint8).t(), sa, sb, out_dtype, b)
+    out = ops.cutlass_scaled_mm(a.cuda(), w.cuda().t(), sa.cuda(), sb.cuda(), out_dtype,
+                                None if b is None else b.cuda())
+    assert out.shape == (M, N) and out.dtype == out_dtype
+    rtol = 1.6e-2 if out_dtype == torch.bfloat16 else 2e-3
+    torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=rtol, atol=5e-3)
+
+
+@pytest.mark.parametrize("M", [1, 33, 64, 128, 257, 512])
+@pytest.mark.parametrize("N", [256, 971, 4096])
+@pytest.mark.parametrize("K", [128, 496, 1024])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
+def test_scaled_mm_shapes(ops, oracle, M, N, K, out_dtype):
+    check(ops, oracle, M, N, K, True, True, out_dtype, bias=(N == 971), seed=M + N + K)
+
+
+@pytest.mark.parametrize("per_token", [False, True])
+@pytest.mark.parametrize("per_channel", [False, True])
+@pytest.mark.parametrize("bias", [False, True])
+def test_scaled_mm_scale_kinds(ops, oracle, per_token, per_channel, bias):
+    check(ops, oracle, 96, 384, 512, per_token, per_channel, torch.bfloat16, bias, seed=3)
+
+
+def test_scaled_mm_integer_exact(ops, oracle):
+    """Asymmetric small-integer operands: every product and sum is exact, so the
+    result must match to the bit (catches any operand-layout / transpose error)."""
+    M, N, K = 128, 256, 256
+    g = torch.Generator().manual_seed(1)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    a[:, 0] = torch.arange(M).float() % 7
+    w[:, 1] = torch.arange(N).float() % 5
+    a8, w8 = a.to(torch.float8_e4m3fn), w.to(torch.float8_e4m3fn)
+    one = torch.ones((1, 1))
+    out = ops.cutlass_scaled_mm(a8.cuda(), w8.cuda().t(), one.cuda(), one.cuda(), torch.float16)
+    ref = (a @ w.t())
+    assert torch.equal(out.cpu().float(), ref.to(torch.float16).float())
+
+
+@pytest.mark.parametrize("KN", [(4096, 6144), (14336, 4096)])
+@pytest.mark.parametrize("M", [1, 16, 256])
+def test_scaled_mm_llama_shapes(ops, oracle, KN, M):
+    K, N = KN
+    check(ops, oracle, M, N, K, True, True, torch.bfloat16, False, seed=K + M)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("mk", [(256, 1024), (4096, 4096), (1000, 512)])
+def test_wvSplitKQ(ops, oracle, n, mk):
+    """vs the oracle's scaled_mm restatement with per-tensor scales
+    (reference test: tests/kernels/quantization/test_rocm_skinny_gemms.py:57-82, rtol 1e-2)."""
+    m, k = mk
+    g = torch.Generator().manual_seed(n + m)
+    A = (torch.rand((n, k), generator=g) - 0.5).to(torch.float8_e4m3fn)   # activations
+    B = (torch.rand((m, k), generator=g) - 0.5).to(torch.float8_e4m3fn)   # weights
+    sa, sb = torch.tensor([0.7]), torch.tensor([1.3])
+    out = ops.wvSplitKQ(B.cuda(), A.cuda(), torch.bfloat16, sb.cuda(), sa.cuda(), 256)
+    assert out.shape == (n, m)
+    ref = oracle.scaled_mm(A.view(torch.uint8), B.view(torch.uint8).t(), sa, sb, torch.bfloat16)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=1e-2, atol=1e-3)

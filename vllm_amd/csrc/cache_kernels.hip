@@ -1,0 +1,353 @@
+// KV-cache writes for the paged cache: reshape_and_cache, reshape_and_cache_flash,
+// convert_fp8, copy_blocks.  Pure HBM-bound byte movement (+ e4m3 conversion):
+// every thread moves 16-byte vectors on the contiguous side of each layout.
+//
+// Semantics follow the reference operators cited in include/vllm_amd.h
+// (csrc/cache_kernels.cu:210-306, 505-576, 71-170); the kernels themselves are
+// written for wave64 / 16-byte accesses and share no structure with them.
+#include "common.cuh"
+
+namespace va {
+
+template <typename T, int N> struct alignas(sizeof(T) * N) Vec { T v[N]; };
+
+// ---------------------------------------------------------------------------
+// reshape_and_cache: K -> [blk, h, d/x, off, x]  V -> [blk, h, d, off]
+// One workgroup per token; one thread per x-chunk (x elements = one 16-byte
+// cache vector of K).  The K store is a single 16-byte (or x*sizeof) vector,
+// the V stores are the layout's inherent element scatter (stride block_size).
+// ---------------------------------------------------------------------------
+template <typename scalar_t, typename cache_t, bool FP8, int X>
+__global__ void reshape_and_cache_kernel(
+    const scalar_t* __restrict__ key, const scalar_t* __restrict__ value,
+    cache_t* __restrict__ key_cache, cache_t* __restrict__ value_cache,
+    const int64_t* __restrict__ slot_mapping, int64_t key_stride,
+    int64_t value_stride, int num_heads, int head_size, int block_size,
+    const float* __restrict__ k_scale_p, const float* __restrict__ v_scale_p) {
+  const int64_t token = blockIdx.x;
+  const int64_t slot = slot_mapping[token];
+  if (slot < 0) return;
+  const int64_t blk = slot / block_size;
+  const int64_t off = slot % block_size;
+  const int chunks_per_head = head_size / X;
+  const int nchunks = num_heads * chunks_per_head;
+  float ks = 1.f, vs = 1.f;
+  if constexpr (FP8) { ks = *k_scale_p; vs = *v_scale_p; }
+
+  const scalar_t* krow = key + token * key_stride;
+  const scalar_t* vrow = value + token * value_stride;
+  const int64_t blk_elems = (int64_t)num_heads * head_size * block_size;
+
+  for (int c = threadIdx.x; c < nchunks; c += blockDim.x) {
+    const int h = c / chunks_per_head;
+    const int xc = c % chunks_per_head;
+    const int src = h * head_size + xc * X;
+    Vec<scalar_t, X> kv = *reinterpret_cast<const Vec<scalar_t, X>*>(krow + src);
+    Vec<scalar_t, X> vv = *reinterpret_cast<const Vec<scalar_t, X>*>(vrow + src);
+    const int64_t kdst = blk * blk_elems + (int64_t)h * head_size * block_size +
+                         (int64_t)xc * block_size * X + off * X;
+    const int64_t vdst = blk * blk_elems + (int64_t)h * head_size * block_size +
+                         (int64_t)(xc * X) * block_size + off;
+    if constexpr (FP8) {
+      Vec<uint8_t, X> kq;
+#pragma unroll
+      for (int j = 0; j < X; ++j) kq.v[j] = f32_to_fp8(kv_quant_prep(kv.v[j], ks));
+      *reinterpret_cast<Vec<uint8_t, X>*>(key_cache + kdst) = kq;
+#pragma unroll
+      for (int j = 0; j < X; ++j)
+        value_cache[vdst + (int64_t)j * block_size] = f32_to_fp8(kv_quant_prep(vv.v[j], vs));
+    } else {
+      *reinterpret_cast<Vec<scalar_t, X>*>(key_cache + kdst) = kv;
+#pragma unroll
+      for (int j = 0; j < X; ++j) value_cache[vdst + (int64_t)j * block_size] = vv.v[j];
+    }
+  }
+}
+
+// Scalar fallback for layouts / alignments the vector kernel does not cover
+// (odd x, misaligned rows).  Same mapping as the reference element loop.
+template <typename scalar_t, typename cache_t, bool FP8>
+__global__ void reshape_and_cache_scalar_kernel(
+    const scalar_t* __restrict__ key, const scalar_t* __restrict__ value,
+    cache_t* __restrict__ key_cache, cache_t* __restrict__ value_cache,
+    const int64_t* __restrict__ slot_mapping, int64_t key_stride,
+    int64_t value_stride, int num_heads, int head_size, int block_size, int x,
+    const float* __restrict__ k_scale_p, const float* __restrict__ v_scale_p) {
+  const int64_t token = blockIdx.x;
+  const int64_t slot = slot_mapping[token];
+  if (slot < 0) return;
+  const int64_t blk = slot / block_size;
+  const int64_t off = slot % block_size;
+  float ks = 1.f, vs = 1.f;
+  if constexpr (FP8) { ks = *k_scale_p; vs = *v_scale_p; }
+  const int n = num_heads * head_size;
+  const int64_t blk_elems = (int64_t)n * block_size;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int h = i / head_size, d = i % head_size;
+    const int64_t kdst = blk * blk_elems + (int64_t)h * head_size * block_size +
+                         (int64_t)(d / x) * block_size * x + off * x + d % x;
+    const int64_t vdst = blk * blk_elems + (int64_t)h * head_size * block_size +
+                         (int64_t)d * block_size + off;
+    scalar_t k = key[token * key_stride + i];
+    scalar_t v = value[token * value_stride + i];
+    if constexpr (FP8) {
+      key_cache[kdst] = f32_to_fp8(kv_quant_prep(k, ks));
+      value_cache[vdst] = f32_to_fp8(kv_quant_prep(v, vs));
+    } else {
+      key_cache[kdst] = k;
+      value_cache[vdst] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// reshape_and_cache_flash: K,V -> [blk, off, h, d] through explicit strides.
+// One thread per VEC contiguous head elements: both sides are 16-byte vectors.
+// ---------------------------------------------------------------------------
+template <typename scalar_t, typename cache_t, bool FP8, int VEC>
+__global__ void reshape_and_cache_flash_kernel(
+    const scalar_t* __restrict__ key, const scalar_t* __restrict__ value,
+    cache_t* __restrict__ key_cache, cache_t* __restrict__ value_cache,
+    const int64_t* __restrict__ slot_mapping, int64_t block_stride,
+    int64_t page_stride, int64_t head_stride, int64_t key_stride,
+    int64_t value_stride, int num_heads, int head_size, int block_size,
+    const float* __restrict__ k_scale_p, const float* __restrict__ v_scale_p) {
+  const int64_t token = blockIdx.x;
+  const int64_t slot = slot_mapping[token];
+  if (slot < 0) return;
+  const int64_t blk = slot / block_size;
+  const int64_t off = slot % block_size;
+  float ks = 1.f, vs = 1.f;
+  if constexpr (FP8) { ks = *k_scale_p; vs = *v_scale_p; }
+  const int vec_per_head = head_size / VEC;
+  const int nvec = num_heads * vec_per_head;
+  const scalar_t* krow = key + token * key_stride;
+  const scalar_t* vrow = value + token * value_stride;
+  for (int c = threadIdx.x; c < nvec; c += blockDim.x) {
+    const int h = c / vec_per_head;
+    const int d = (c % vec_per_head) * VEC;
+    const int src = h * head_size + d;
+    const int64_t dst = blk * block_stride + off * page_stride + h * head_stride + d;
+    Vec<scalar_t, VEC> kv = *reinterpret_cast<const Vec<scalar_t, VEC>*>(krow + src);
+    Vec<scalar_t, VEC> vv = *reinterpret_cast<const Vec<scalar_t, VEC>*>(vrow + src);
+    if constexpr (FP8) {
+      Vec<uint8_t, VEC> kq, vq;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        kq.v[j] = f32_to_fp8(kv_quant_prep(kv.v[j], ks));
+        vq.v[j] = f32_to_fp8(kv_quant_prep(vv.v[j], vs));
+      }
+      *reinterpret_cast<Vec<uint8_t, VEC>*>(key_cache + dst) = kq;
+      *reinterpret_cast<Vec<uint8_t, VEC>*>(value_cache + dst) = vq;
+    } else {
+      *reinterpret_cast<Vec<scalar_t, VEC>*>(key_cache + dst) = kv;
+      *reinterpret_cast<Vec<scalar_t, VEC>*>(value_cache + dst) = vv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// convert_fp8 (test helper in the reference, also used to build fp8 caches)
+// ---------------------------------------------------------------------------
+template <typename scalar_t, bool TO_FP8>
+__global__ void convert_fp8_kernel(void* __restrict__ dst_, const void* __restrict__ src_,
+                                   int64_t n, float scale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if constexpr (TO_FP8) {
+      const scalar_t* src = (const scalar_t*)src_;
+      ((uint8_t*)dst_)[i] = f32_to_fp8(kv_quant_prep(src[i], scale));
+    } else {
+      const uint8_t* src = (const uint8_t*)src_;
+      ((scalar_t*)dst_)[i] = from_f32<scalar_t>(fp8_to_f32(src[i]) * scale);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// copy_blocks: grid (pair, 2 {K,V}); 16-byte vectors
+// ---------------------------------------------------------------------------
+__global__ void copy_blocks_kernel(uint8_t* __restrict__ kc, uint8_t* __restrict__ vc,
+                                   const int64_t* __restrict__ mapping, int64_t block_bytes) {
+  const int64_t src = mapping[2 * blockIdx.x];
+  const int64_t dst = mapping[2 * blockIdx.x + 1];
+  uint8_t* base = blockIdx.y == 0 ? kc : vc;
+  const uint8_t* s = base + src * block_bytes;
+  uint8_t* d = base + dst * block_bytes;
+  if ((block_bytes & 15) == 0 && (((uintptr_t)base) & 15) == 0) {
+    const int64_t nv = block_bytes >> 4;
+    for (int64_t i = threadIdx.x; i < nv; i += blockDim.x)
+      reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+  } else {
+    for (int64_t i = threadIdx.x; i < block_bytes; i += blockDim.x) d[i] = s[i];
+  }
+}
+
+}  // namespace va
+
+using namespace va;
+
+static inline bool aligned(const void* p, size_t a) { return (((uintptr_t)p) & (a - 1)) == 0; }
+
+template <typename scalar_t, bool FP8>
+static int launch_reshape_and_cache(const void* key, const void* value, void* kc, void* vc,
+                                    const int64_t* slot_mapping, int num_tokens, int num_heads,
+                                    int head_size, int block_size, int x, int64_t key_stride,
+                                    int64_t value_stride, const float* ks, const float* vs,
+                                    hipStream_t st) {
+  typedef typename std::conditional<FP8, uint8_t, scalar_t>::type cache_t;
+  constexpr int XN = FP8 ? 16 : 16 / (int)sizeof(scalar_t);  // natural x
+  const bool vec_ok = (x == XN) && (head_size % x == 0) &&
+                      (key_stride % x == 0) && (value_stride % x == 0) &&
+                      aligned(key, sizeof(scalar_t) * XN) && aligned(value, sizeof(scalar_t) * XN) &&
+                      aligned(kc, 16);
+  if (vec_ok) {
+    const int nchunks = num_heads * head_size / x;
+    int threads = nchunks < 256 ? ((nchunks + 63) / 64) * 64 : 256;
+    hipLaunchKernelGGL((reshape_and_cache_kernel<scalar_t, cache_t, FP8, XN>), dim3(num_tokens),
+                       dim3(threads), 0, st, (const scalar_t*)key, (const scalar_t*)value,
+                       (cache_t*)kc, (cache_t*)vc, slot_mapping, key_stride, value_stride,
+                       num_heads, head_size, block_size, ks, vs);
+  } else {
+    int n = num_heads * head_size;
+    int threads = n < 512 ? ((n + 63) / 64) * 64 : 512;
+    hipLaunchKernelGGL((reshape_and_cache_scalar_kernel<scalar_t, cache_t, FP8>),
+                       dim3(num_tokens), dim3(threads), 0, st, (const scalar_t*)key,
+                       (const scalar_t*)value, (cache_t*)kc, (cache_t*)vc, slot_mapping,
+                       key_stride, value_stride, num_heads, head_size, block_size, x, ks, vs);
+  }
+  VA_LAUNCH_CHECK("reshape_and_cache launch");
+  return VLLM_AMD_OK;
+}
+
+extern "C" int vllm_amd_reshape_and_cache(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size, int block_size,
+    int x, int64_t key_stride, int64_t value_stride, int dtype, int kv_dtype,
+    const float* k_scale, const float* v_scale, void* stream) {
+  VA_REQUIRE(num_tokens >= 0 && num_heads > 0 && head_size > 0 && block_size > 0 && x > 0,
+             VLLM_AMD_EINVAL, "reshape_and_cache: bad shape");
+  VA_REQUIRE(head_size % x == 0, VLLM_AMD_EINVAL,
+             "reshape_and_cache: head_size %d not divisible by x %d", head_size, x);
+  if (num_tokens == 0) return VLLM_AMD_OK;
+  VA_REQUIRE(key && value && key_cache && value_cache && slot_mapping, VLLM_AMD_EINVAL,
+             "reshape_and_cache: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+#define RC(T, F) \
+  return launch_reshape_and_cache<T, F>(key, value, key_cache, value_cache, slot_mapping, \
+      num_tokens, num_heads, head_size, block_size, x, key_stride, value_stride, k_scale, v_scale, st)
+  if (kv_dtype == VLLM_AMD_KV_AUTO) {
+    if (dtype == VLLM_AMD_F32) RC(float, false);
+    if (dtype == VLLM_AMD_F16) RC(f16_t, false);
+    if (dtype == VLLM_AMD_BF16) RC(bf16_t, false);
+    VA_REQUIRE(false, VLLM_AMD_EUNSUPPORTED, "Unsupported input type of kv cache: %d", dtype);
+  } else if (kv_dtype == VLLM_AMD_KV_FP8_E4M3) {
+    VA_REQUIRE(k_scale && v_scale, VLLM_AMD_EINVAL, "reshape_and_cache: null scale");
+    if (dtype == VLLM_AMD_F32) RC(float, true);
+    if (dtype == VLLM_AMD_F16) RC(f16_t, true);
+    if (dtype == VLLM_AMD_BF16) RC(bf16_t, true);
+    VA_REQUIRE(false, VLLM_AMD_EUNSUPPORTED, "Unsupported input type of kv cache: %d", dtype);
+  }
+#undef RC
+  VA_REQUIRE(false, VLLM_AMD_EUNSUPPORTED, "Unsupported data type of kv cache: %d", kv_dtype);
+}
+
+template <typename scalar_t, bool FP8>
+static int launch_flash(const void* key, const void* value, void* kc, void* vc,
+                        const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+                        int block_size, int64_t key_stride, int64_t value_stride,
+                        int64_t block_stride, int64_t page_stride, int64_t head_stride,
+                        const float* ks, const float* vs, hipStream_t st) {
+  typedef typename std::conditional<FP8, uint8_t, scalar_t>::type cache_t;
+  constexpr int V = 16 / (int)sizeof(scalar_t);  // 16-byte source vectors (4 or 8 elements)
+  const size_t cvb = V * sizeof(cache_t);       // bytes of one cache vector
+  const bool vec_ok = head_size % V == 0 && key_stride % V == 0 && value_stride % V == 0 &&
+                      block_stride % V == 0 && page_stride % V == 0 && head_stride % V == 0 &&
+                      aligned(key, 16) && aligned(value, 16) && aligned(kc, cvb) &&
+                      aligned(vc, cvb);
+#define FL(VEC)                                                                               \
+  do {                                                                                        \
+    const int nvec = num_heads * head_size / VEC;                                             \
+    int threads = nvec < 256 ? ((nvec + 63) / 64) * 64 : 256;                                 \
+    hipLaunchKernelGGL((reshape_and_cache_flash_kernel<scalar_t, cache_t, FP8, VEC>),         \
+                       dim3(num_tokens), dim3(threads), 0, st, (const scalar_t*)key,          \
+                       (const scalar_t*)value, (cache_t*)kc, (cache_t*)vc, slot_mapping,      \
+                       block_stride, page_stride, head_stride, key_stride, value_stride,      \
+                       num_heads, head_size, block_size, ks, vs);                             \
+  } while (0)
+  if (vec_ok) FL(V); else FL(1);
+#undef FL
+  VA_LAUNCH_CHECK("reshape_and_cache_flash launch");
+  return VLLM_AMD_OK;
+}
+
+extern "C" int vllm_amd_reshape_and_cache_flash(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size, int block_size,
+    int64_t key_stride, int64_t value_stride, int64_t block_stride, int64_t page_stride,
+    int64_t head_stride, int dtype, int kv_dtype, const float* k_scale, const float* v_scale,
+    void* stream) {
+  VA_REQUIRE(num_tokens >= 0 && num_heads > 0 && head_size > 0 && block_size > 0,
+             VLLM_AMD_EINVAL, "reshape_and_cache_flash: bad shape");
+  if (num_tokens == 0) return VLLM_AMD_OK;
+  VA_REQUIRE(key && value && key_cache && value_cache && slot_mapping, VLLM_AMD_EINVAL,
+             "reshape_and_cache_flash: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+#define RF(T, F) \
+  return launch_flash<T, F>(key, value, key_cache, value_cache, slot_mapping, num_tokens, \
+      num_heads, head_size, block_size, key_stride, value_stride, block_stride, page_stride, \
+      head_stride, k_scale, v_scale, st)
+  if (kv_dtype == VLLM_AMD_KV_AUTO) {
+    if (dtype == VLLM_AMD_F32) RF(float, false);
+    if (dtype == VLLM_AMD_F16) RF(f16_t, false);
+    if (dtype == VLLM_AMD_BF16) RF(bf16_t, false);
+    VA_REQUIRE(false, VLLM_AMD_EUNSUPPORTED, "Unsupported input type of kv cache: %d", dtype);
+  } else if (kv_dtype == VLLM_AMD_KV_FP8_E4M3) {
+    VA_REQUIRE(k_scale && v_scale, VLLM_AMD_EINVAL, "reshape_and_cache_flash: null scale");
+    if (dtype == VLLM_AMD_F32) RF(float, true);
+    if (dtype == VLLM_AMD_F16) RF(f16_t, true);
+    if (dtype == VLLM_AMD_BF16) RF(bf16_t, true);
+    VA_REQUIRE(false, VLLM_AMD_EUNSUPPORTED, "Unsupported input type of kv cache: %d", dtype);
+  }
+#undef RF
+  VA_REQUIRE(false, VLLM_AMD_EUNSUPPORTED, "Unsupported data type of kv cache: %d", kv_dtype);
+}
+
+extern "C" int vllm_amd_convert_fp8(void* dst, const void* src, int64_t n, float scale, int dtype,
+                                    int to_fp8, void* stream) {
+  VA_REQUIRE(n >= 0, VLLM_AMD_EINVAL, "convert_fp8: negative size");
+  if (n == 0) return VLLM_AMD_OK;
+  VA_REQUIRE(dst && src, VLLM_AMD_EINVAL, "convert_fp8: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+#define CV(T)                                                                                 \
+  do {                                                                                        \
+    if (to_fp8)                                                                               \
+      hipLaunchKernelGGL((convert_fp8_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, \
+                         st, dst, src, n, scale);                                             \
+    else                                                                                      \
+      hipLaunchKernelGGL((convert_fp8_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, \
+                         st, dst, src, n, scale);                                             \
+  } while (0)
+  if (dtype == VLLM_AMD_F32) CV(float);
+  else if (dtype == VLLM_AMD_F16) CV(f16_t);
+  else if (dtype == VLLM_AMD_BF16) CV(bf16_t);
+  else VA_REQUIRE(false, VLLM_AMD_EUNSUPPORTED, "Unsupported data type: %d", dtype);
+#undef CV
+  VA_LAUNCH_CHECK("convert_fp8 launch");
+  return VLLM_AMD_OK;
+}
+
+extern "C" int vllm_amd_copy_blocks(void* key_cache, void* value_cache,
+                                    const int64_t* block_mapping, int num_pairs,
+                                    int64_t block_bytes, void* stream) {
+  VA_REQUIRE(num_pairs >= 0 && block_bytes > 0, VLLM_AMD_EINVAL, "copy_blocks: bad shape");
+  if (num_pairs == 0) return VLLM_AMD_OK;
+  VA_REQUIRE(key_cache && value_cache && block_mapping, VLLM_AMD_EINVAL,
+             "copy_blocks: null pointer");
+  hipLaunchKernelGGL(copy_blocks_kernel, dim3(num_pairs, 2), dim3(256), 0, (hipStream_t)stream,
+                     (uint8_t*)key_cache, (uint8_t*)value_cache, block_mapping, block_bytes);
+  VA_LAUNCH_CHECK("copy_blocks launch");
+  return VLLM_AMD_OK;
+}

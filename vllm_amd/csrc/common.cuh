@@ -1,0 +1,95 @@
+// Shared device/host helpers for libvllm_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vllm_amd.h"
+
+namespace va {
+
+// ---- host side: error reporting ------------------------------------------
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+int hip_fail(hipError_t e, const char* what);
+
+#define VA_REQUIRE(cond, code, ...)   \
+  do {                                \
+    if (!(cond)) {                    \
+      ::va::set_error(__VA_ARGS__);   \
+      return (code);                  \
+    }                                 \
+  } while (0)
+
+#define VA_LAUNCH_CHECK(what)                              \
+  do {                                                     \
+    hipError_t e__ = hipGetLastError();                    \
+    if (e__ != hipSuccess) return ::va::hip_fail(e__, what); \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int dtype_size(int dt) { return dt == VLLM_AMD_F32 ? 4 : 2; }
+
+// ---- device side: scalar types --------------------------------------------
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+template <int DT> struct Scalar;
+template <> struct Scalar<VLLM_AMD_F32> { typedef float type; };
+template <> struct Scalar<VLLM_AMD_F16> { typedef f16_t type; };
+template <> struct Scalar<VLLM_AMD_BF16> { typedef bf16_t type; };
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+// float -> T, round-to-nearest-even (v_cvt_pk_bf16_f32 / v_cvt_f16_f32)
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// ---- device side: OCP fp8 e4m3fn ------------------------------------------
+__device__ __forceinline__ float fp8_to_f32(uint8_t b) {
+  return __builtin_amdgcn_cvt_f32_fp8((int)b, 0);
+}
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// bytes [2*hi, 2*hi+1] of w -> two floats
+__device__ __forceinline__ f32x2 fp8x2_to_f32(uint32_t w, bool hi) {
+  return hi ? __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true)
+            : __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
+}
+// Round-to-nearest-even with finite saturation: the arithmetic of
+// __hip_cvt_float_to_fp8(v, __HIP_SATFINITE, __HIP_E4M3) on gfx950 (NaN/Inf
+// skip the clamp), which is what the reference's fp8::scaled_convert and
+// fp8::cvt_c10 reduce to (csrc/quantization/fp8/amd/quant_utils.cuh:29-40).
+__device__ __forceinline__ float fp8_clamp(float v) {
+  uint32_t u = __float_as_uint(v);
+  return ((u & 0x7f800000u) != 0x7f800000u)
+             ? __builtin_amdgcn_fmed3f(v, 448.0f, -448.0f)
+             : v;
+}
+__device__ __forceinline__ uint8_t f32_to_fp8(float v) {
+  v = fp8_clamp(v);
+  return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(v, v, 0, false) & 0xff);
+}
+// four floats -> four packed e4m3 bytes (a -> byte 0)
+__device__ __forceinline__ uint32_t f32x4_to_fp8x4(float a, float b, float c, float d) {
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_clamp(a), fp8_clamp(b), 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_clamp(c), fp8_clamp(d), r, true);
+  return (uint32_t)r;
+}
+
+// fp8::scaled_convert<uint8_t, scalar_t> (quant_utils.cuh:486-495, 540-547, 585-591):
+// the half path rounds the quotient to half before the fp8 conversion.
+template <typename T> __device__ __forceinline__ float kv_quant_prep(T x, float scale) {
+  float q = to_f32(x) / scale;
+  if constexpr (sizeof(T) == 2 && !__is_same(T, bf16_t)) q = (float)(f16_t)q;
+  return q;
+}
+
+// ---- wave64 reductions ------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+}  // namespace va

@@ -1,0 +1,463 @@
+// Paged attention decode, MI355X bandwidth kernel (gfx950, wave64, MFMA).
+//
+// One workgroup per (sequence, kv head[, partition]) serves ALL q heads of the
+// GQA group, so every K/V byte is read from HBM exactly once.  The work of a
+// workgroup is cut into "steps" of 16 KiB of KV (fp8: 4 tiles of 16 tokens,
+// 16-bit KV: 2 tiles); the NW waves of the workgroup stride over the steps,
+// each keeping a private online-softmax state, and merge through LDS at the end.
+//
+// Per step and wave:
+//   K  16-byte loads straight to VGPRs; for a fixed load index the 64 lanes read
+//      one contiguous 1 KiB of the page ([d-chunk][token][16 B] layout: lane =
+//      (chunk group g4 = lane>>4, token c16 = lane&15)).  fp8 bytes are widened
+//      to the query dtype in registers (exact) and fed as the A operand of
+//      mfma_f32_16x16x32: S^T[token][q head] += K[token][d] * Q^T[d][q head].
+//      The contraction index d is permuted to match what a lane loaded; Q^T is
+//      loaded once per workgroup in the same permutation (B operand).
+//   softmax  S^T has the q head on the lane column, so running max / sum are
+//      lane-local plus two cross-group shuffles; exp2 with log2(e) folded in.
+//   P  rounded to the query dtype (as the reference does), transposed through a
+//      2.25 KiB per-wave LDS tile into the B-operand order of the PV product.
+//   V  16-byte loads of [d][16 tokens]; lane group g4 owns tile g4 of the step;
+//      O^T[d][q head] += V^T[d][token] * P^T[token][q head], 8 d-tiles.
+// The loads of step n+1 are issued as soon as step n's registers are free, so
+// ~16 KiB per wave stay in flight; no LDS staging of K/V (each byte is used by
+// one wave only -- cdna_hip_programming.md "GEMV / M <= 16" rule).
+//
+// Semantics: reference operators paged_attention_v1 / _v2 / ROCm paged_attention
+// (citations in include/vllm_amd.h); fp8 scales folded as in
+// csrc/rocm/attention.cu:514-518, 714-717; partials written in the reference's
+// tmp_out / exp_sums / max_logits layout and merged by pa_reduce_kernel.
+#include "paged_attention.cuh"
+
+#include <float.h>
+
+namespace va {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+template <typename scalar_t> struct Mma;
+template <> struct Mma<bf16_t> {
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  // two e4m3 bytes (half `hi` of w) -> two packed bf16, exact
+  static __device__ __forceinline__ uint32_t cvt2(uint32_t w, bool hi) {
+    bf16x2 r = hi ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true)
+                  : __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false);
+    return __builtin_bit_cast(uint32_t, r);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    bf16x2 r = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, r);
+  }
+};
+template <> struct Mma<f16_t> {
+  typedef f16x8 frag;
+  static __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t cvt2(uint32_t w, bool hi) {
+    f16x2 r = hi ? __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true)
+                 : __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false);
+    return __builtin_bit_cast(uint32_t, r);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    f16x2 r = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, r);
+  }
+};
+
+// 16 e4m3 bytes -> 2 fragments of 8 16-bit values (bytes 0..7, bytes 8..15)
+template <typename scalar_t>
+__device__ __forceinline__ void widen16(const uint4& raw, uint4& lo, uint4& hi) {
+  lo.x = Mma<scalar_t>::cvt2(raw.x, false);
+  lo.y = Mma<scalar_t>::cvt2(raw.x, true);
+  lo.z = Mma<scalar_t>::cvt2(raw.y, false);
+  lo.w = Mma<scalar_t>::cvt2(raw.y, true);
+  hi.x = Mma<scalar_t>::cvt2(raw.z, false);
+  hi.y = Mma<scalar_t>::cvt2(raw.z, true);
+  hi.z = Mma<scalar_t>::cvt2(raw.w, false);
+  hi.w = Mma<scalar_t>::cvt2(raw.w, true);
+}
+
+// keep the first `valid` (0..16) bytes of a 16-byte vector, zero the rest
+__device__ __forceinline__ uint4 mask_bytes(uint4 v, int valid) {
+  auto m = [&](int w) -> uint32_t {
+    int r = valid - 4 * w;
+    return r >= 4 ? 0xffffffffu : (r <= 0 ? 0u : ((1u << (8 * r)) - 1u));
+  };
+  v.x &= m(0); v.y &= m(1); v.z &= m(2); v.w &= m(3);
+  return v;
+}
+// keep the first `valid` (0..8) 16-bit elements
+__device__ __forceinline__ uint4 mask_halfs(uint4 v, int valid) {
+  auto m = [&](int w) -> uint32_t {
+    int r = valid - 2 * w;
+    return r >= 2 ? 0xffffffffu : (r <= 0 ? 0u : 0x0000ffffu);
+  };
+  v.x &= m(0); v.y &= m(1); v.z &= m(2); v.w &= m(3);
+  return v;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr int kPRowBytes = 144;  // P tile row (one q head): 64 tok * 2 B + 16 B pad
+
+template <typename scalar_t, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int NW>
+__global__ __launch_bounds__(NW * 64) void pa_mfma_kernel(
+    scalar_t* __restrict__ out, float* __restrict__ exp_sums, float* __restrict__ max_logits,
+    const scalar_t* __restrict__ q, const uint8_t* __restrict__ k_cache,
+    const uint8_t* __restrict__ v_cache, int num_heads, int num_kv_heads, float scale,
+    const int* __restrict__ block_tables, const int* __restrict__ seq_lens,
+    const int* __restrict__ query_start_loc, int max_num_blocks_per_seq,
+    const float* __restrict__ alibi_slopes, int64_t q_stride, int64_t kv_block_bytes,
+    int64_t kv_head_bytes, const float* __restrict__ k_scale_p,
+    const float* __restrict__ v_scale_p, int partition_size, int max_parts, int gqa_chunks) {
+  constexpr int ES = FP8 ? 1 : 2;             // cache element bytes
+  constexpr int TILES = FP8 ? 4 : 2;          // 16-token tiles per step
+  constexpr int STEP_TOK = TILES * 16;
+  constexpr int DT = HEAD_SIZE / 16;          // d-tiles of the PV product
+  constexpr int KL = HEAD_SIZE * ES / 64;     // K loads per tile and lane (16 B each)
+  constexpr int SUBS = BLOCK_SIZE / 16;       // tiles per page
+  constexpr int K_CHUNK_BYTES = BLOCK_SIZE * 16;   // one d-chunk of a page: [BS tok][16 B]
+  constexpr int V_ROW_BYTES = BLOCK_SIZE * ES;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c16 = lane & 15, g4 = lane >> 4;
+
+  // blockIdx.x = ((seq * num_kv_heads + kvh) * gqa_chunks + chunk), blockIdx.y = partition
+  const int chunk = blockIdx.x % gqa_chunks;
+  const int kvh = (blockIdx.x / gqa_chunks) % num_kv_heads;
+  const int seq = blockIdx.x / (gqa_chunks * num_kv_heads);
+  const int part = blockIdx.y;
+  const int G = num_heads / num_kv_heads;
+  const int head0 = kvh * G + chunk * 16;        // first q head of this workgroup
+  const int nheads = min(16, G - chunk * 16);    // q heads served (columns in use)
+
+  int64_t qrow = seq;
+  if (query_start_loc) {
+    if (query_start_loc[seq + 1] - query_start_loc[seq] != 1) return;
+    qrow = query_start_loc[seq];
+  }
+  const int seq_len = seq_lens[seq];
+  const bool partitioned = partition_size > 0;
+  const int start_tok = partitioned ? part * partition_size : 0;
+  if (partitioned && start_tok >= seq_len) return;
+  const int end_tok = partitioned ? min(start_tok + partition_size, seq_len) : seq_len;
+  const int nsteps = (end_tok - start_tok + STEP_TOK - 1) / STEP_TOK;
+  const int last_page = seq_len > 0 ? (seq_len - 1) / BLOCK_SIZE : 0;
+  const int* bt = block_tables + (int64_t)seq * max_num_blocks_per_seq;
+
+  float kscale = 1.f, vscale = 1.f;
+  if constexpr (FP8) { kscale = *k_scale_p; vscale = *v_scale_p; }
+  const float sc2 = scale * kscale * kLog2e;
+  const bool col_ok = c16 < nheads;
+  const float slope2 = (alibi_slopes && col_ok) ? alibi_slopes[head0 + c16] * kLog2e : 0.f;
+
+  // ---- LDS: per-wave P tile, then (aliased) the cross-wave merge buffers ------
+  constexpr int P_BYTES = 16 * kPRowBytes;                       // 2304
+  constexpr int MERGE_BYTES = NW * HEAD_SIZE * 16 * 4 + NW * 16 * 8;
+  constexpr int LDS_BYTES = (NW * P_BYTES > MERGE_BYTES) ? NW * P_BYTES : MERGE_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  char* p_tile = lds + wave * P_BYTES;
+
+  // ---- Q^T fragments (B operand of QK), permuted like the K loads -------------
+  // fp8 : load i of a tile gives d = 16*(g4 + 4*i) + [0,16): two k-steps (lo/hi 8)
+  // 16b : load i gives d = 8*(g4 + 4*i) + [0,8): one k-step
+  constexpr int QF = HEAD_SIZE / 32;  // k-steps of the QK product
+  uint4 qf[QF];
+  {
+    const scalar_t* qp = q + qrow * q_stride + (int64_t)(head0 + c16) * HEAD_SIZE;
+#pragma unroll
+    for (int s = 0; s < QF; ++s) {
+      int d;
+      if constexpr (FP8) d = 16 * (g4 + 4 * (s >> 1)) + 8 * (s & 1);
+      else d = 8 * (g4 + 4 * s);
+      qf[s] = col_ok ? *reinterpret_cast<const uint4*>(qp + d) : make_uint4(0, 0, 0, 0);
+    }
+  }
+
+  // ---- running state ------------------------------------------------------------
+  float m_run = -FLT_MAX;   // running max (log2 units), uniform over g4 for a column
+  float l_run = 0.f;        // this lane's partial sum of exp
+  f32x4 o[DT];
+#pragma unroll
+  for (int m = 0; m < DT; ++m) o[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 kreg[TILES * KL];
+  uint4 vreg[DT * (FP8 ? 1 : 1)];
+
+  auto page_of_tile = [&](int tile) -> int {   // tile index within the sequence
+    int pg = tile / SUBS;
+    return pg > last_page ? last_page : pg;
+  };
+  auto issue_k = [&](int step) {
+    const int tile0 = (start_tok >> 4) + step * TILES;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const int tile = tile0 + t;
+      const int64_t pb = bt[page_of_tile(tile)];
+      const uint8_t* base = k_cache + pb * kv_block_bytes + (int64_t)kvh * kv_head_bytes +
+                            (tile % SUBS) * 256;
+#pragma unroll
+      for (int i = 0; i < KL; ++i)
+        kreg[t * KL + i] = *reinterpret_cast<const uint4*>(
+            base + (g4 + 4 * i) * K_CHUNK_BYTES + c16 * 16);
+    }
+  };
+  auto issue_v = [&](int step) {
+    const int tile0 = (start_tok >> 4) + step * TILES;
+    // lane group g4 owns tile (FP8: g4, 16-bit: g4>>1) of the step
+    const int tsel = FP8 ? g4 : (g4 >> 1);
+    int pb_sel = 0;
+    int sub_sel = 0;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const int tile = tile0 + t;
+      const int pb = bt[page_of_tile(tile)];
+      if (t == tsel) { pb_sel = pb; sub_sel = tile % SUBS; }
+    }
+    const uint8_t* base = v_cache + (int64_t)pb_sel * kv_block_bytes +
+                          (int64_t)kvh * kv_head_bytes + sub_sel * 16 * ES +
+                          (FP8 ? 0 : (g4 & 1) * 16);
+#pragma unroll
+    for (int m = 0; m < DT; ++m)
+      vreg[m] = *reinterpret_cast<const uint4*>(base + (16 * m + c16) * V_ROW_BYTES);
+  };
+
+  if (wave < nsteps) { issue_k(wave); issue_v(wave); }
+
+  for (int step = wave; step < nsteps; step += NW) {
+    const int tok0 = start_tok + step * STEP_TOK;
+    // ---------------- S^T = K Q^T -------------------------------------------------
+    f32x4 s[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KL; ++i) {
+        if constexpr (FP8) {
+          uint4 lo, hi;
+          widen16<scalar_t>(kreg[t * KL + i], lo, hi);
+          acc = Mma<scalar_t>::mfma(lo, qf[2 * i], acc);
+          acc = Mma<scalar_t>::mfma(hi, qf[2 * i + 1], acc);
+        } else {
+          acc = Mma<scalar_t>::mfma(kreg[t * KL + i], qf[i], acc);
+        }
+      }
+      s[t] = acc;
+    }
+    const bool more = step + NW < nsteps;
+    if (more) issue_k(step + NW);
+
+    // ---------------- online softmax ----------------------------------------------
+    // lane holds S^T[token = tok0 + 16 t + 4 g4 + r][q head c16]
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tok = tok0 + 16 * t + 4 * g4 + r;
+        float v = s[t][r] * sc2 + slope2 * (float)(tok - seq_len + 1);
+        v = tok < end_tok ? v : -FLT_MAX;
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = fast_exp2(m_run - m_new);   // first step: exp2(-huge) = 0
+    m_run = m_new;
+    float psum = 0.f;
+    uint32_t pk[TILES][2];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      float p[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tok = tok0 + 16 * t + 4 * g4 + r;
+        float e = fast_exp2(s[t][r] - m_new);
+        e = tok < end_tok ? e : 0.f;
+        p[r] = e;
+        psum += e;
+      }
+      pk[t][0] = Mma<scalar_t>::pack2(p[0], p[1]);
+      pk[t][1] = Mma<scalar_t>::pack2(p[2], p[3]);
+    }
+    l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int m = 0; m < DT; ++m) o[m] *= alpha;
+    }
+
+    // ---------------- P^T through LDS ------------------------------------------------
+    // write: row = q head c16, tokens 16 t + 4 g4 .. +3   (8 bytes)
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      uint2 w = make_uint2(pk[t][0], pk[t][1]);
+      *reinterpret_cast<uint2*>(p_tile + c16 * kPRowBytes + (16 * t + 4 * g4) * 2) = w;
+    }
+    uint4 plo, phi;
+    if constexpr (FP8) {
+      // lane group g4 consumes tile g4: tokens 16 g4 + [0,8) and + [8,16)
+      plo = *reinterpret_cast<const uint4*>(p_tile + c16 * kPRowBytes + (16 * g4) * 2);
+      phi = *reinterpret_cast<const uint4*>(p_tile + c16 * kPRowBytes + (16 * g4 + 8) * 2);
+    } else {
+      // tile g4>>1, tokens 8 (g4&1) + [0,8)  ==  step tokens 8 g4 + [0,8)
+      plo = *reinterpret_cast<const uint4*>(p_tile + c16 * kPRowBytes + (8 * g4) * 2);
+      phi = plo;
+    }
+
+    // ---------------- O^T += V^T P^T ----------------------------------------------------
+    // tail: zero V of tokens >= end_tok (their P is 0, but stale bytes may be NaN)
+    const int vt0 = FP8 ? tok0 + 16 * g4 : tok0 + 8 * g4;   // first token of this lane's V vector
+    const int vvalid = end_tok - vt0;                        // may be <= 0 or >= 16
+    const bool tail = tok0 + STEP_TOK > end_tok;             // wave-uniform
+#pragma unroll
+    for (int m = 0; m < DT; ++m) {
+      uint4 raw = vreg[m];
+      if constexpr (FP8) {
+        if (tail) raw = mask_bytes(raw, vvalid);
+        uint4 lo, hi;
+        widen16<scalar_t>(raw, lo, hi);
+        o[m] = Mma<scalar_t>::mfma(lo, plo, o[m]);
+        o[m] = Mma<scalar_t>::mfma(hi, phi, o[m]);
+      } else {
+        if (tail) raw = mask_halfs(raw, vvalid);
+        o[m] = Mma<scalar_t>::mfma(raw, plo, o[m]);
+      }
+    }
+    if (more) issue_v(step + NW);
+  }
+
+  // ---------------- merge the NW waves ------------------------------------------------
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  __syncthreads();   // P tiles are dead; LDS becomes the merge buffer
+  float* om = reinterpret_cast<float*>(lds);                         // [NW][HEAD_SIZE][16]
+  float* ml = om + NW * HEAD_SIZE * 16;                               // [NW][16][2]
+  if (g4 == 0) {
+    ml[(wave * 16 + c16) * 2 + 0] = m_run;
+    ml[(wave * 16 + c16) * 2 + 1] = l_run;
+  }
+  __syncthreads();
+  float m_tot = -FLT_MAX;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) m_tot = fmaxf(m_tot, ml[(w * 16 + c16) * 2]);
+  const float f_w = fast_exp2(m_run - m_tot);   // waves with no step: m_run = -FLT_MAX -> 0
+#pragma unroll
+  for (int m = 0; m < DT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      om[(wave * HEAD_SIZE + 16 * m + 4 * g4 + r) * 16 + c16] = o[m][r] * f_w;
+  __syncthreads();
+
+  // thread -> (q head qh, 8 consecutive d)
+  constexpr int TPH = HEAD_SIZE / 8;             // threads per head row
+  const int qh = threadIdx.x / TPH;
+  const int d0 = (threadIdx.x % TPH) * 8;
+  if (qh < nheads) {
+    // l_tot / m_tot of column qh live in lanes with c16 == qh; recompute from LDS
+    float mt = -FLT_MAX;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mt = fmaxf(mt, ml[(w * 16 + qh) * 2]);
+    float lt = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) lt += ml[(w * 16 + qh) * 2 + 1] * fast_exp2(ml[(w * 16 + qh) * 2] - mt);
+    const float inv = __fdividef(1.f, lt + 1e-6f) * vscale;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) a += om[(w * HEAD_SIZE + d0 + j) * 16 + qh];
+      acc[j] = a * inv;
+    }
+    uint4 pk;
+    pk.x = Mma<scalar_t>::pack2(acc[0], acc[1]);
+    pk.y = Mma<scalar_t>::pack2(acc[2], acc[3]);
+    pk.z = Mma<scalar_t>::pack2(acc[4], acc[5]);
+    pk.w = Mma<scalar_t>::pack2(acc[6], acc[7]);
+    const int head = head0 + qh;
+    int64_t oidx;
+    if (partitioned) {
+      const int64_t sidx = ((int64_t)seq * num_heads + head) * max_parts + part;
+      oidx = sidx * HEAD_SIZE + d0;
+      if (d0 == 0) {
+        max_logits[sidx] = mt * kLn2;
+        exp_sums[sidx] = lt;
+      }
+    } else {
+      oidx = ((int64_t)qrow * num_heads + head) * HEAD_SIZE + d0;
+    }
+    *reinterpret_cast<uint4*>(out + oidx) = pk;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+bool paged_attention_mfma_supported(const PagedAttnParams& p) {
+  if (p.dtype != VLLM_AMD_F16 && p.dtype != VLLM_AMD_BF16) return false;
+  if (p.head_size != 128 && p.head_size != 64) return false;
+  if (p.block_size != 16 && p.block_size != 32) return false;
+  if (p.bs_vert_stride > 1) return false;                 // block-sparse -> generic
+  if (p.partition_size > 0 && p.partition_size % 64 != 0) return false;
+  const int es = p.kv_dtype == VLLM_AMD_KV_AUTO ? 2 : 1;
+  // natural contiguous page layout per (block, head)
+  if (p.kv_head_stride != (int64_t)p.head_size * p.block_size) return false;
+  if ((p.q_stride * 2) % 16 != 0 || (((uintptr_t)p.query) & 15) != 0) return false;
+  if ((((uintptr_t)p.out) & 15) != 0) return false;
+  if (p.tmp_out && (((uintptr_t)p.tmp_out) & 15) != 0) return false;
+  (void)es;
+  return true;
+}
+
+template <typename scalar_t, bool FP8, int HS, int BS>
+static int launch_mfma(const PagedAttnParams& p) {
+  constexpr int NW = 4;
+  const int G = p.num_heads / p.num_kv_heads;
+  const int chunks = ceil_div(G, 16);
+  const int es = FP8 ? 1 : 2;
+  const bool part = p.partition_size > 0;
+  dim3 grid((unsigned)(p.num_seqs * p.num_kv_heads * chunks), part ? p.max_num_partitions : 1);
+  void* out = part ? p.tmp_out : p.out;
+  hipLaunchKernelGGL((pa_mfma_kernel<scalar_t, FP8, HS, BS, NW>), grid, dim3(NW * 64), 0, p.stream,
+                     (scalar_t*)out, p.exp_sums, p.max_logits, (const scalar_t*)p.query,
+                     (const uint8_t*)p.key_cache, (const uint8_t*)p.value_cache, p.num_heads,
+                     p.num_kv_heads, p.scale, p.block_tables, p.seq_lens, p.query_start_loc,
+                     p.max_num_blocks_per_seq, p.alibi_slopes, p.q_stride,
+                     p.kv_block_stride * es, p.kv_head_stride * es, p.k_scale, p.v_scale,
+                     p.partition_size, p.max_num_partitions, chunks);
+  VA_LAUNCH_CHECK("paged_attention mfma launch");
+  if (part) return paged_attention_reduce(p);
+  return VLLM_AMD_OK;
+}
+
+template <typename scalar_t>
+static int dispatch_mfma(const PagedAttnParams& p) {
+  const bool fp8 = p.kv_dtype == VLLM_AMD_KV_FP8_E4M3;
+#define L(HS, BS) return fp8 ? launch_mfma<scalar_t, true, HS, BS>(p) : launch_mfma<scalar_t, false, HS, BS>(p)
+  if (p.head_size == 128 && p.block_size == 16) L(128, 16);
+  if (p.head_size == 128 && p.block_size == 32) L(128, 32);
+  if (p.head_size == 64 && p.block_size == 16) L(64, 16);
+  if (p.head_size == 64 && p.block_size == 32) L(64, 32);
+#undef L
+  VA_REQUIRE(false, VLLM_AMD_EUNSUPPORTED, "paged_attention mfma: unsupported shape");
+}
+
+int paged_attention_mfma(const PagedAttnParams& p) {
+  if (p.dtype == VLLM_AMD_F16) return dispatch_mfma<f16_t>(p);
+  return dispatch_mfma<bf16_t>(p);
+}
+
+}  // namespace va
