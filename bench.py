@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the MI355X quantized decode hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-extra]
+
+One "step" = one pass of the hot path over one batch of synthetic input: a
+paged-attention decode call (through torch.ops -> C ABI -> HIP) on
+BASELINE.json configs[1]: Llama-3-8B shape, fp8 e4m3 KV with per-tensor scales,
+batch 64, ctx 4096, 32 q / 8 kv heads, head 128, block 16, bf16 query/output.
+Inputs are resident in HBM before the timed region.  `value` = algorithmic bytes
+(K and V once + q/out + block tables + seq_lens) / time.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): attention shards by
+KV head with no collective, so every rank runs the same per-GPU
+shape on its own shard ("weak" scaling); value = bytes of all ranks / max time.
+
+The JSON line also carries
+  roofline      dominant kernel vs the 8 TB/s HBM3E peak, HIP-event timed
+  cpu_baseline  the reference's own CPU paged_attention_v1 (oracle/_ref, built
+                from /root/reference/csrc/cpu by oracle/Makefile) on configs[0],
+                timed on the host cores of this box; falls back to our C port
+  extra         fp8 scaled_mm TFLOP/s at Llama-3-8B shapes (configs[2]), cache
+                write / quant GB/s, and (N>1) row-parallel GEMM + RCCL all-reduce
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP8_DENSE_PEAK_TFLOPS = 5000.0  # MI355X_MICROARCH.md: fp8 MFMA ~5 PF dense (block-scaled form)
+
+
+def make_attention_inputs(S, ctx, H, KVH, D, BS, kv_fp8, device, seed=0, n_caches=2):
+    """Synthetic decode batch: q ~ U(-d^-.5, d^-.5) bf16, KV of the
+    same distribution quantised to e4m3 with scale 1.0, all seq_lens = ctx,
+    distinct random physical blocks."""
+    from vllm_amd import _custom_ops as ops
+    g = torch.Generator(device=device).manual_seed(seed)
+    sc = D ** -0.5
+    nb_seq = (ctx + BS - 1) // BS
+    NB = S * nb_seq
+    x = 16 if kv_fp8 else 8
+    caches = []
+    for _ in range(n_caches):
+        kc16 = (torch.rand((NB, KVH, D // x, BS, x), generator=g, device=device) * 2 - 1) * sc
+        vc16 = (torch.rand((NB, KVH, D, BS), generator=g, device=device) * 2 - 1) * sc
+        if kv_fp8:
+            kc = torch.empty(kc16.shape, dtype=torch.uint8, device=device)
+            vc = torch.empty(vc16.shape, dtype=torch.uint8, device=device)
+            ops.convert_fp8(kc, kc16.to(torch.bfloat16), 1.0, "fp8")
+            ops.convert_fp8(vc, vc16.to(torch.bfloat16), 1.0, "fp8")
+        else:
+            kc, vc = kc16.to(torch.bfloat16), vc16.to(torch.bfloat16)
+        del kc16, vc16
+        caches.append((kc, vc))
+    q = ((torch.rand((S, H, D), generator=g, device=device) * 2 - 1) * sc).to(torch.bfloat16)
+    perm = torch.randperm(NB, generator=g, device=device).to(torch.int32)
+    bt = perm.view(S, nb_seq).contiguous()
+    sl = torch.full((S,), ctx, dtype=torch.int32, device=device)
+    one = torch.ones(1, dtype=torch.float32, device=device)
+    return q, caches, bt, sl, one
+
+
+def attention_bytes(S, ctx, H, KVH, D, BS, kv_bytes):
+    kv = S * KVH * ctx * D * 2 * kv_bytes
+    qo = S * H * D * (2 + 2)
+    tables = S * ((ctx + BS - 1) // BS) * 4 + 4 * S
+    return kv + qo + tables
+
+
+def time_gpu(fn, steps, warmup, dist=None):
+    """W untimed + K timed calls bracketed by barrier + synchronize; returns
+    (wall seconds, HIP-event seconds) for the K steps."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    return t1 - t0, e0.elapsed_time(e1) * 1e-3
+
+
+def run_attention(cfg, steps, warmup, device, dist=None, version="auto"):
+    from vllm_amd import _custom_ops as ops
+    from vllm_amd.attention.paged_attn import PagedAttention
+    S, ctx, H, KVH, D, BS = cfg["S"], cfg["ctx"], cfg["H"], cfg["KVH"], cfg["D"], cfg["BS"]
+    fp8 = cfg["kv"] == "fp8"
+    q, caches, bt, sl, one = make_attention_inputs(S, ctx, H, KVH, D, BS, fp8, device)
+    kvd = "fp8" if fp8 else "auto"
+    state = {"i": 0}
+
+    def step():
+        kc, vc = caches[state["i"] % len(caches)]
+        state["i"] += 1
+        return PagedAttention.forward_decode(q, kc, vc, bt, sl, ctx, kvd, KVH, D ** -0.5, None,
+                                             one, one)
+
+    wall, ev = time_gpu(step, steps, warmup, dist)
+    nbytes = attention_bytes(S, ctx, H, KVH, D, BS, 1 if fp8 else 2)
+    return dict(wall=wall, event=ev, bytes=nbytes)
+
+
+def run_scaled_mm(device, shapes, Ms, iters=20):
+    from vllm_amd import _custom_ops as ops
+    res = []
+    for (K, N) in shapes:
+        w = torch.randn((N, K), device=device, dtype=torch.bfloat16)
+        wq, ws = ops.scaled_fp8_quant(w, use_per_token_if_dynamic=True)
+        del w
+        for M in Ms:
+            a = torch.randn((M, K), device=device, dtype=torch.bfloat16)
+            aq, as_ = ops.scaled_fp8_quant(a, use_per_token_if_dynamic=True)
+            fn = lambda: ops.cutlass_scaled_mm(aq, wq.t(), as_, ws, torch.bfloat16)
+            _, ev = time_gpu(fn, iters, 3)
+            t = ev / iters
+            flops = 2.0 * M * N * K
+            nbytes = M * K + K * N + 2 * M * N + 4 * (M + N)
+            bound = min(FP8_DENSE_PEAK_TFLOPS, HBM_PEAK_GBPS * 1e9 * (flops / nbytes) / 1e12)
+            res.append(dict(M=M, K=K, N=N, us=round(t * 1e6, 2), tflops=round(flops / t / 1e12, 2),
+                            gbps=round(nbytes / t / 1e9, 1), roof_tflops=round(bound, 1),
+                            frac=round(flops / t / 1e12 / bound, 4)))
+    return res
+
+
+def run_cache_quant(device, iters=20):
+    from vllm_amd import _custom_ops as ops
+    out = {}
+    # decode-step cache write at configs[1]: T=64 tokens ... plus a prefill-sized one
+    for name, T in (("decode_T64", 64), ("prefill_T8192", 8192)):
+        KVH, D, BS = 8, 128, 16
+        NB = max(T // BS * 2, 64)
+        k = torch.randn((T, KVH, D), device=device, dtype=torch.bfloat16)
+        v = torch.randn_like(k)
+        kc = torch.zeros((NB, KVH, D // 16, BS, 16), dtype=torch.uint8, device=device)
+        vc = torch.zeros((NB, KVH, D, BS), dtype=torch.uint8, device=device)
+        slots = torch.randperm(NB * BS, device=device)[:T].to(torch.int64)
+        sc = torch.tensor([0.05], device=device)
+        fn = lambda: ops.reshape_and_cache(k, v, kc, vc, slots, "fp8", sc, sc)
+        _, ev = time_gpu(fn, iters, 3)
+        nbytes = T * KVH * D * (2 * 2 + 2 * 1) + 8 * T
+        out["reshape_and_cache_fp8_" + name] = dict(us=round(ev / iters * 1e6, 2),
+                                                    gbps=round(nbytes / (ev / iters) / 1e9, 1))
+    for M, K in ((64, 4096), (4096, 4096), (4096, 14336)):
+        x = torch.randn((M, K), device=device, dtype=torch.bfloat16)
+        fn = lambda: ops.scaled_fp8_quant(x, use_per_token_if_dynamic=True)
+        _, ev = time_gpu(fn, iters, 3)
+        nbytes = M * K * 3 + 4 * M
+        out[f"per_token_quant_M{M}_K{K}"] = dict(us=round(ev / iters * 1e6, 2),
+                                                 gbps=round(nbytes / (ev / iters) / 1e9, 1))
+    return out
+
+
+def cpu_baseline():
+    """Reference CPU paged_attention_v1 on BASELINE.json configs[0] (32 seqs, ctx 1024,
+    32q/8kv, d 128, block 16, bf16 KV), all host cores available to this process."""
+    from oracle import oracle as O
+    S, ctx, H, KVH, D, BS = 32, 1024, 32, 8, 128, 16
+    g = torch.Generator().manual_seed(0)
+    sc = D ** -0.5
+    nb_seq = ctx // BS
+    NB = S * nb_seq
+    kc = ((torch.rand((NB, KVH, D // 8, BS, 8), generator=g) * 2 - 1) * sc).to(torch.bfloat16)
+    vc = ((torch.rand((NB, KVH, D, BS), generator=g) * 2 - 1) * sc).to(torch.bfloat16)
+    q = ((torch.rand((S, H, D), generator=g) * 2 - 1) * sc).to(torch.bfloat16)
+    bt = torch.randperm(NB, generator=g).to(torch.int32).view(S, nb_seq).contiguous()
+    sl = torch.full((S,), ctx, dtype=torch.int32)
+    one = torch.ones(1)
+    out = torch.empty_like(q)
+    threads = torch.get_num_threads()
+    if O.load_ref():
+        kind = "reference"
+        fn = lambda: torch.ops.refcpu.paged_attention_v1(out, q, kc, vc, KVH, sc, bt, sl, BS, ctx,
+                                                         None, "auto", one, one, 0, 0, 0, 64, 0)
+    else:
+        kind = "port"
+        fn = lambda: O.paged_attention_v1(out, q, kc, vc, KVH, sc, bt, sl, BS, ctx, None, "auto",
+                                          1.0, 1.0)
+    fn()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        fn()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n >= 100000:
+            break
+    per = el / n
+    nbytes = attention_bytes(S, ctx, H, KVH, D, BS, 2)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count()
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    used = omp if omp > 0 else min(threads, cores)
+    return dict(value=round(nbytes / per / 1e9, 2), unit="GB/s", cores=used, kind=kind,
+                ms_per_iter=round(per * 1e3, 3),
+                sample=f"configs[0]: paged_attention_v1 CPU, 32 seqs x ctx 1024, 32q/8kv, d128, "
+                       f"block 16, bf16 KV; {n} iterations in {el:.1f} s on {used} OpenMP threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-extra", action="store_true", help="skip scaled_mm / cache / cpu legs")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    # configs[1]; per-GPU shape is the same at every N (head-sharded, weak scaling)
+    cfg = dict(S=64, ctx=4096, H=32, KVH=8, D=128, BS=16, kv="fp8")
+    r = run_attention(cfg, args.steps, args.warmup, device, dist)
+    wall = r["wall"]
+    if world > 1:
+        t = torch.tensor([wall, r["event"]], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ev = t.tolist()
+    else:
+        ev = r["event"]
+    total_bytes = r["bytes"] * world * args.steps
+    value = total_bytes / wall / 1e9
+    per_launch = ev / args.steps
+    achieved = r["bytes"] / per_launch / 1e9
+
+    line = {
+        "metric": "paged-attn decode HBM GB/s (% peak) + fp8 scaled_mm TFLOPS at 1/2/4/8 GPUs",
+        "value": round(value, 1),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "fp8_e4m3 KV / bf16 q,out / f32 accumulate",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: Llama-3-8B-shape decode paged attention, fp8 e4m3 KV "
+                               "(per-tensor scales), batch 64, ctx 4096, 32q/8kv heads, head 128, "
+                               "block 16, per GPU",
+                   "op": "PagedAttention.forward_decode -> paged_attention_v1 (pa_mfma_kernel)",
+                   "parallelism": f"kv-head sharded x{world}, no collective"},
+        "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBPS, 2),
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "kernel": "pa_mfma_kernel<bf16, fp8, 128, 16>",
+                     "us_per_launch": round(per_launch * 1e6, 2),
+                     "algorithmic_bytes_per_launch": r["bytes"]},
+    }
+
+    if rank == 0 and not args.no_extra:
+        extra = {}
+        if world == 1:
+            shapes = [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)]
+            extra["scaled_mm"] = run_scaled_mm(device, shapes, [1, 16, 64, 256, 1024, 4096])
+            best = max(extra["scaled_mm"], key=lambda e: e["tflops"])
+            extra["scaled_mm_best_tflops"] = best["tflops"]
+            extra["scaled_mm_pct_of_fp8_peak"] = round(100 * best["tflops"] / FP8_DENSE_PEAK_TFLOPS, 2)
+            extra["cache_quant"] = run_cache_quant(device)
+            line["cpu_baseline"] = cpu_baseline()
+        line["extra"] = extra
+    if world > 1:
+        from vllm_amd.distributed import bench_row_parallel
+        rp = bench_row_parallel(device, dist)
+        if rank == 0:
+            line.setdefault("extra", {})["row_parallel_tp"] = rp
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

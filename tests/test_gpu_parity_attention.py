@@ -93,6 +93,8 @@ def test_mfma_shapes(ops, oracle, version, kv, hs_bs):
 @pytest.mark.parametrize("hs_bs", [(80, 16), (256, 8), (120, 32), (32, 16), (192, 16), (96, 8), (112, 16)])
 def test_generic_path(ops, oracle, version, kv, dtype, hs_bs):
     hs, bs = hs_bs
+    if kv != "auto" and hs % 16:
+        pytest.skip("fp8 cache needs head_size % 16 == 0 (x = 16), as in the reference tests")
     c = make_attn_case(5, 8, 4, hs, bs, dtype, kv, [1, 7, 130, 515, 700], seed=3,
                        kv_scale=1.0 if kv == "auto" else 0.5, alibi=(bs == 16))
     run_case(ops, oracle, c, version)

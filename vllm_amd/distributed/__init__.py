@@ -1,0 +1,103 @@
+"""Tensor-parallel pieces of the hot path: KV-head sharding of
+attention (no collective), column/row-parallel fp8 linear, and the single SUM
+all-reduce at the row-parallel boundary (vllm/model_executor/layers/linear.py
+:1385-1389 -> RCCL ncclAllReduce on the compute stream, pynccl.py:110-133).
+
+One process per GPU; ``torch.distributed`` backend "nccl" is RCCL on ROCm, "gloo"
+is used by the CPU tests of the sharding logic."""
+from __future__ import annotations
+
+import torch
+
+
+def shard_range(total: int, world: int, rank: int) -> tuple[int, int]:
+    """[start, end) of a dimension split evenly over ranks (linear.py divide())."""
+    if total % world != 0:
+        raise ValueError(f"{total} is not divisible by {world}")
+    per = total // world
+    return rank * per, (rank + 1) * per
+
+
+def shard_kv_heads(num_heads: int, num_kv_heads: int, world: int, rank: int):
+    """Heads owned by `rank` (QKVParallelLinear, linear.py:886): each rank gets
+    num_kv_heads/world KV heads and their GQA group of q heads.  KV-head
+    replication (world > num_kv_heads) is the reference's behaviour for that case
+    and out of scope here."""
+    if num_kv_heads % world != 0:
+        raise ValueError("num_kv_heads must be divisible by the TP world size")
+    kv0, kv1 = shard_range(num_kv_heads, world, rank)
+    g = num_heads // num_kv_heads
+    return (kv0 * g, kv1 * g), (kv0, kv1)
+
+
+def tensor_model_parallel_all_reduce(x: torch.Tensor, dist=None, group=None) -> torch.Tensor:
+    """communication_op.py:12-14: out-of-place SUM over the TP group."""
+    if dist is None:
+        import torch.distributed as dist  # type: ignore
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return x
+    out = x.clone()
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    return out
+
+
+def row_parallel_fp8_linear(x_shard: torch.Tensor, wq_shard: torch.Tensor,
+                            w_scale: torch.Tensor, dist=None, group=None,
+                            linear_op=None) -> torch.Tensor:
+    """RowParallelLinear.forward with a PTPC fp8 weight (linear.py:1369-1397):
+    the activation shard [M, K/world] is quantised per token ON THIS RANK's shard
+    (reference behaviour: quant runs inside apply() on input_parallel), multiplied
+    with the [N, K/world] fp8 weight shard, then summed over ranks."""
+    from ..quantization import Fp8LinearOp
+    op = linear_op or Fp8LinearOp()
+    partial = op.apply(x_shard, wq_shard.t(), w_scale, out_dtype=x_shard.dtype)
+    return tensor_model_parallel_all_reduce(partial, dist, group)
+
+
+def bench_row_parallel(device, dist, M: int = 256, hidden: int = 8192, iters: int = 20):
+    """configs[3] GEMM + all-reduce legs: row-parallel fp8 GEMMs (K per GPU 1024 and
+    3584 at TP8) and the RCCL all-reduce of the [256, 8192] bf16 result."""
+    import time
+    from .. import _custom_ops as ops
+    world = dist.get_world_size()
+    res = {}
+    for name, K_full in (("o_proj", 8192), ("down_proj", 28672)):
+        Ks = K_full // 8  # per-GPU K of the TP8 Llama-3-70B shard (weight_shapes.py:58-63 / 8)
+        w = torch.randn((hidden, Ks), device=device, dtype=torch.bfloat16)
+        wq, ws = ops.scaled_fp8_quant(w, use_per_token_if_dynamic=True)
+        x = torch.randn((M, Ks), device=device, dtype=torch.bfloat16)
+
+        def gemm_only():
+            xq, xs = ops.scaled_fp8_quant(x, use_per_token_if_dynamic=True)
+            return ops.cutlass_scaled_mm(xq, wq.t(), xs, ws, torch.bfloat16)
+
+        def full():
+            y = gemm_only()
+            dist.all_reduce(y)
+            return y
+
+        for tag, fn in (("quant_gemm_us", gemm_only), ("quant_gemm_allreduce_us", full)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize(); dist.barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / iters], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            res[f"{name}_K{Ks}_{tag}"] = round(t.item() * 1e6, 2)
+    y = torch.randn((M, hidden), device=device, dtype=torch.bfloat16)
+    for _ in range(3):
+        dist.all_reduce(y)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dist.all_reduce(y)
+    torch.cuda.synchronize()
+    t = torch.tensor([(time.perf_counter() - t0) / iters], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    nbytes = y.numel() * 2
+    res["allreduce_4MiB_us"] = round(t.item() * 1e6, 2)
+    res["allreduce_bus_gbps"] = round(2 * (world - 1) / world * nbytes / t.item() / 1e9, 1)
+    return res
