@@ -199,6 +199,16 @@ int vllm_amd_wvSplitKQ(const void* in_a, const void* in_b, void* out_c,
                        int K_in, int N_in, int out_dtype, int cu_count,
                        void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* Tuning knobs (no counterpart in the reference): used by tools/ and bench   */
+/* scripts to A/B kernel variants inside one process.                          */
+/*   "pa_variant": bit 0 = non-temporal K/V loads, bit 1 = two steps of K/V    */
+/*                 registers in flight (not instantiated, measured slower)     */
+/*   "pa_sp":      reference partitions merged per workgroup in v2 / rocm      */
+/*                 launches (0 = heuristic, paged_attention_mfma.hip)          */
+/* ------------------------------------------------------------------------- */
+int vllm_amd_set_tuning(const char* key, int value);
+
 #ifdef __cplusplus
 }
 #endif

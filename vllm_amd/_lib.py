@@ -41,6 +41,7 @@ SIGNATURES = {
     "vllm_amd_scaled_mm": [
         _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _vp],
     "vllm_amd_wvSplitKQ": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "vllm_amd_set_tuning": [C.c_char_p, _i],
 }
 
 
@@ -68,3 +69,7 @@ def check(rc: int) -> None:
     """Turn a negative status into the RuntimeError the reference's TORCH_CHECK raises."""
     if rc != 0:
         raise RuntimeError(lib.vllm_amd_last_error().decode())
+
+
+def set_tuning(key: str, value: int) -> None:
+    check(lib.vllm_amd_set_tuning(key.encode(), int(value)))

@@ -20,6 +20,7 @@ struct PagedAttnParams {
   int max_num_blocks_per_seq, block_size, max_seq_len;
   int partition_size;      // 0 = v1 (no partitioning)
   int max_num_partitions;  // P (1 for v1)
+  int sp_parts = 1;        // reference partitions merged per workgroup / scratch slot stride
   const float* alibi_slopes;
   int dtype, kv_dtype;
   const float* k_scale;
@@ -37,6 +38,9 @@ int paged_attention_generic(const PagedAttnParams& p);
 // VLLM_AMD_EUNSUPPORTED *without touching memory* when the shape is not covered.
 bool paged_attention_mfma_supported(const PagedAttnParams& p);
 int paged_attention_mfma(const PagedAttnParams& p);
+// tuning knob (A/B measurements): see vllm_amd_set_tuning
+void set_pa_variant(int v);
+void set_pa_sp(int v);
 // Split-K merge of partitions (v2 / rocm).
 int paged_attention_reduce(const PagedAttnParams& p);
 

@@ -20,6 +20,7 @@
 #include "paged_attention.cuh"
 
 #include <float.h>
+#include <string.h>
 
 namespace va {
 
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(128) void pa_reduce_kernel(
     const float* __restrict__ max_logits, const scalar_t* __restrict__ tmp_out,
     const int* __restrict__ seq_lens, const int* __restrict__ query_start_loc,
     const float* __restrict__ fp8_out_scale, int head_size, int partition_size,
-    int max_num_partitions) {
+    int max_num_partitions, int slot_stride) {
   const int head = blockIdx.x, seq = blockIdx.y, num_heads = gridDim.x;
   const int tid = threadIdx.x;
   int64_t orow = seq;
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(128) void pa_reduce_kernel(
     orow = query_start_loc[seq];
   }
   const int seq_len = seq_lens[seq];
+  // partition_size = tokens per USED scratch slot; used slots are slot_stride apart
   const int np = (seq_len + partition_size - 1) / partition_size;
   const int64_t sidx = ((int64_t)seq * num_heads + head) * max_num_partitions;
   const scalar_t* tp = tmp_out + sidx * head_size;
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(128) void pa_reduce_kernel(
   __shared__ float red[4];
   float m = -FLT_MAX;
   for (int j = tid; j < np; j += 128) {
-    float l = max_logits[sidx + j];
+    float l = max_logits[sidx + (int64_t)j * slot_stride];
     w[j] = l;
     m = fmaxf(m, l);
   }
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(128) void pa_reduce_kernel(
   m = fmaxf(red[0], red[1]);
   float g = 0.f;
   for (int j = tid; j < np; j += 128) {
-    float r = exp_sums[sidx + j] * expf(w[j] - m);
+    float r = exp_sums[sidx + (int64_t)j * slot_stride] * expf(w[j] - m);
     w[j] = r;
     g += r;
   }
@@ -293,10 +295,10 @@ __global__ __launch_bounds__(128) void pa_reduce_kernel(
   for (int i = tid; i < head_size; i += 128) {
     float acc = 0.f;
     if constexpr (!ROCM) {
-      for (int j = 0; j < np; ++j) acc += to_f32(tp[(int64_t)j * head_size + i]) * w[j] * inv;
+      for (int j = 0; j < np; ++j) acc += to_f32(tp[(int64_t)j * slot_stride * head_size + i]) * w[j] * inv;
       out[i] = from_f32<scalar_t>(acc);
     } else {
-      for (int j = 0; j < np; ++j) acc += to_f32(tp[(int64_t)j * head_size + i]) * w[j];
+      for (int j = 0; j < np; ++j) acc += to_f32(tp[(int64_t)j * slot_stride * head_size + i]) * w[j];
       acc *= inv;
       if (fp8_out_scale) {
         acc *= 1.0f / (*fp8_out_scale);
@@ -315,13 +317,13 @@ static int launch_reduce(const PagedAttnParams& p) {
   if (p.rocm_semantics)
     hipLaunchKernelGGL((pa_reduce_kernel<scalar_t, true>), grid, dim3(128), smem, p.stream, p.out,
                        p.exp_sums, p.max_logits, (const scalar_t*)p.tmp_out, p.seq_lens,
-                       p.query_start_loc, p.fp8_out_scale, p.head_size, p.partition_size,
-                       p.max_num_partitions);
+                       p.query_start_loc, p.fp8_out_scale, p.head_size, p.partition_size * p.sp_parts,
+                       p.max_num_partitions, p.sp_parts);
   else
     hipLaunchKernelGGL((pa_reduce_kernel<scalar_t, false>), grid, dim3(128), smem, p.stream, p.out,
                        p.exp_sums, p.max_logits, (const scalar_t*)p.tmp_out, p.seq_lens,
-                       p.query_start_loc, p.fp8_out_scale, p.head_size, p.partition_size,
-                       p.max_num_partitions);
+                       p.query_start_loc, p.fp8_out_scale, p.head_size, p.partition_size * p.sp_parts,
+                       p.max_num_partitions, p.sp_parts);
   VA_LAUNCH_CHECK("paged_attention reduce launch");
   return VLLM_AMD_OK;
 }
@@ -506,4 +508,12 @@ extern "C" int vllm_amd_paged_attention_rocm(
              "paged_attention: max_num_partitions %d too small for max_context_len %d",
              max_num_partitions, max_context_len);
   return run(p, "paged_attention");
+}
+
+// Tuning knobs for A/B measurements in one process (not part of the reference surface).
+extern "C" int vllm_amd_set_tuning(const char* key, int value) {
+  VA_REQUIRE(key != nullptr, VLLM_AMD_EINVAL, "set_tuning: null key");
+  if (strcmp(key, "pa_variant") == 0) { set_pa_variant(value); return VLLM_AMD_OK; }
+  if (strcmp(key, "pa_sp") == 0) { set_pa_sp(value); return VLLM_AMD_OK; }
+  VA_REQUIRE(false, VLLM_AMD_EINVAL, "set_tuning: unknown key %s", key);
 }

@@ -31,6 +31,7 @@
 #include "paged_attention.cuh"
 
 #include <float.h>
+#include <stdlib.h>
 
 namespace va {
 
@@ -110,10 +111,15 @@ __device__ __forceinline__ uint4 mask_halfs(uint4 v, int valid) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
+constexpr int kDefaultVariant = 1;   // set from measurements, see DESIGN.md
 constexpr int kPRowBytes = 144;  // P tile row (one q head): 64 tok * 2 B + 16 B pad
 
-template <typename scalar_t, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int NW>
-__global__ __launch_bounds__(NW * 64) void pa_mfma_kernel(
+// VARIANT bit 0: non-temporal K/V loads; bit 1: two steps of K/V registers in flight
+// Partitioned launches (v2 / rocm): blockIdx.y = super-partition of `slot_stride` reference
+// partitions (partition_size = its token count); the partial result goes to scratch slot
+// blockIdx.y * slot_stride, the slots in between are not used (see launch_mfma_v).
+template <typename scalar_t, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int NW, int VARIANT>
+__global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
     scalar_t* __restrict__ out, float* __restrict__ exp_sums, float* __restrict__ max_logits,
     const scalar_t* __restrict__ q, const uint8_t* __restrict__ k_cache,
     const uint8_t* __restrict__ v_cache, int num_heads, int num_kv_heads, float scale,
@@ -121,7 +127,8 @@ __global__ __launch_bounds__(NW * 64) void pa_mfma_kernel(
     const int* __restrict__ query_start_loc, int max_num_blocks_per_seq,
     const float* __restrict__ alibi_slopes, int64_t q_stride, int64_t kv_block_bytes,
     int64_t kv_head_bytes, const float* __restrict__ k_scale_p,
-    const float* __restrict__ v_scale_p, int partition_size, int max_parts, int gqa_chunks) {
+    const float* __restrict__ v_scale_p, int partition_size, int max_parts, int gqa_chunks,
+    int slot_stride) {
   constexpr int ES = FP8 ? 1 : 2;             // cache element bytes
   constexpr int TILES = FP8 ? 4 : 2;          // 16-token tiles per step
   constexpr int STEP_TOK = TILES * 16;
@@ -194,14 +201,26 @@ __global__ __launch_bounds__(NW * 64) void pa_mfma_kernel(
 #pragma unroll
   for (int m = 0; m < DT; ++m) o[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  uint4 kreg[TILES * KL];
-  uint4 vreg[DT * (FP8 ? 1 : 1)];
+  constexpr bool NT = (VARIANT & 1) != 0;
+  constexpr bool DEEP = (VARIANT & 2) != 0;
+  typedef uint4 KRegs[TILES * KL];
+  typedef uint4 VRegs[DT];
+  KRegs kregA, kregB;
+  VRegs vregA, vregB;
+  auto ld16 = [&](const uint8_t* p) -> uint4 {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4* q4 = reinterpret_cast<const u32x4*>(p);
+    u32x4 r;
+    if constexpr (NT) r = __builtin_nontemporal_load(q4);
+    else r = *q4;
+    return make_uint4(r.x, r.y, r.z, r.w);
+  };
 
   auto page_of_tile = [&](int tile) -> int {   // tile index within the sequence
     int pg = tile / SUBS;
     return pg > last_page ? last_page : pg;
   };
-  auto issue_k = [&](int step) {
+  auto issue_k = [&](KRegs& kreg, int step) {
     const int tile0 = (start_tok >> 4) + step * TILES;
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
@@ -211,11 +230,10 @@ __global__ __launch_bounds__(NW * 64) void pa_mfma_kernel(
                             (tile % SUBS) * 256;
 #pragma unroll
       for (int i = 0; i < KL; ++i)
-        kreg[t * KL + i] = *reinterpret_cast<const uint4*>(
-            base + (g4 + 4 * i) * K_CHUNK_BYTES + c16 * 16);
+        kreg[t * KL + i] = ld16(base + (g4 + 4 * i) * K_CHUNK_BYTES + c16 * 16);
     }
   };
-  auto issue_v = [&](int step) {
+  auto issue_v = [&](VRegs& vreg, int step) {
     const int tile0 = (start_tok >> 4) + step * TILES;
     // lane group g4 owns tile (FP8: g4, 16-bit: g4>>1) of the step
     const int tsel = FP8 ? g4 : (g4 >> 1);
@@ -232,12 +250,12 @@ __global__ __launch_bounds__(NW * 64) void pa_mfma_kernel(
                           (FP8 ? 0 : (g4 & 1) * 16);
 #pragma unroll
     for (int m = 0; m < DT; ++m)
-      vreg[m] = *reinterpret_cast<const uint4*>(base + (16 * m + c16) * V_ROW_BYTES);
+      vreg[m] = ld16(base + (16 * m + c16) * V_ROW_BYTES);
   };
 
-  if (wave < nsteps) { issue_k(wave); issue_v(wave); }
-
-  for (int step = wave; step < nsteps; step += NW) {
+  // one step of the online-softmax recurrence on the registers of (kreg, vreg);
+  // `pf` = the step whose K/V are loaded into the same registers once they are free
+  auto do_step = [&](KRegs& kreg, VRegs& vreg, int step, int pf) {
     const int tok0 = start_tok + step * STEP_TOK;
     // ---------------- S^T = K Q^T -------------------------------------------------
     f32x4 s[TILES];
@@ -257,8 +275,8 @@ __global__ __launch_bounds__(NW * 64) void pa_mfma_kernel(
       }
       s[t] = acc;
     }
-    const bool more = step + NW < nsteps;
-    if (more) issue_k(step + NW);
+    const bool more = pf < nsteps;
+    if (more) issue_k(kreg, pf);
 
     // ---------------- online softmax ----------------------------------------------
     // lane holds S^T[token = tok0 + 16 t + 4 g4 + r][q head c16]
@@ -338,7 +356,18 @@ __global__ __launch_bounds__(NW * 64) void pa_mfma_kernel(
         o[m] = Mma<scalar_t>::mfma(raw, plo, o[m]);
       }
     }
-    if (more) issue_v(step + NW);
+    if (more) issue_v(vreg, pf);
+  };
+
+  if (wave < nsteps) { issue_k(kregA, wave); issue_v(vregA, wave); }
+  if constexpr (DEEP) {
+    if (wave + NW < nsteps) { issue_k(kregB, wave + NW); issue_v(vregB, wave + NW); }
+    for (int step = wave; step < nsteps; step += 2 * NW) {
+      do_step(kregA, vregA, step, step + 2 * NW);
+      if (step + NW < nsteps) do_step(kregB, vregB, step + NW, step + 3 * NW);
+    }
+  } else {
+    for (int step = wave; step < nsteps; step += NW) do_step(kregA, vregA, step, step + NW);
   }
 
   // ---------------- merge the NW waves ------------------------------------------------
@@ -392,7 +421,7 @@ __global__ __launch_bounds__(NW * 64) void pa_mfma_kernel(
     const int head = head0 + qh;
     int64_t oidx;
     if (partitioned) {
-      const int64_t sidx = ((int64_t)seq * num_heads + head) * max_parts + part;
+      const int64_t sidx = ((int64_t)seq * num_heads + head) * max_parts + (int64_t)part * slot_stride;
       oidx = sidx * HEAD_SIZE + d0;
       if (d0 == 0) {
         max_logits[sidx] = mt * kLn2;
@@ -422,25 +451,51 @@ bool paged_attention_mfma_supported(const PagedAttnParams& p) {
   return true;
 }
 
-template <typename scalar_t, bool FP8, int HS, int BS>
-static int launch_mfma(const PagedAttnParams& p) {
+static int g_pa_variant = -1;
+static int pa_variant() {
+  if (g_pa_variant < 0) {
+    const char* e = getenv("VLLM_AMD_PA_VARIANT");
+    g_pa_variant = e ? atoi(e) & 3 : kDefaultVariant;
+  }
+  return g_pa_variant;
+}
+void set_pa_variant(int v) { g_pa_variant = v & 3; }
+static int g_pa_sp = 0;
+void set_pa_sp(int v) { g_pa_sp = v; }
+
+template <typename scalar_t, bool FP8, int HS, int BS, int VARIANT>
+static int launch_mfma_v(const PagedAttnParams& p) {
   constexpr int NW = 4;
   const int G = p.num_heads / p.num_kv_heads;
   const int chunks = ceil_div(G, 16);
   const int es = FP8 ? 1 : 2;
   const bool part = p.partition_size > 0;
-  dim3 grid((unsigned)(p.num_seqs * p.num_kv_heads * chunks), part ? p.max_num_partitions : 1);
+  const int sp = part ? p.sp_parts : 1;   // reference partitions per super-partition
+  dim3 grid((unsigned)(p.num_seqs * p.num_kv_heads * chunks),
+            part ? ceil_div(p.max_num_partitions, sp) : 1);
   void* out = part ? p.tmp_out : p.out;
-  hipLaunchKernelGGL((pa_mfma_kernel<scalar_t, FP8, HS, BS, NW>), grid, dim3(NW * 64), 0, p.stream,
-                     (scalar_t*)out, p.exp_sums, p.max_logits, (const scalar_t*)p.query,
-                     (const uint8_t*)p.key_cache, (const uint8_t*)p.value_cache, p.num_heads,
-                     p.num_kv_heads, p.scale, p.block_tables, p.seq_lens, p.query_start_loc,
-                     p.max_num_blocks_per_seq, p.alibi_slopes, p.q_stride,
-                     p.kv_block_stride * es, p.kv_head_stride * es, p.k_scale, p.v_scale,
-                     p.partition_size, p.max_num_partitions, chunks);
+#define PA_ARGS                                                                                  \
+  (scalar_t*)out, p.exp_sums, p.max_logits, (const scalar_t*)p.query,                           \
+      (const uint8_t*)p.key_cache, (const uint8_t*)p.value_cache, p.num_heads, p.num_kv_heads,  \
+      p.scale, p.block_tables, p.seq_lens, p.query_start_loc, p.max_num_blocks_per_seq,         \
+      p.alibi_slopes, p.q_stride, p.kv_block_stride * es, p.kv_head_stride * es, p.k_scale,     \
+      p.v_scale, p.partition_size * sp, p.max_num_partitions, chunks, sp
+  hipLaunchKernelGGL((pa_mfma_kernel<scalar_t, FP8, HS, BS, NW, VARIANT>), grid, dim3(NW * 64), 0,
+                     p.stream, PA_ARGS);
+#undef PA_ARGS
   VA_LAUNCH_CHECK("paged_attention mfma launch");
   if (part) return paged_attention_reduce(p);
   return VLLM_AMD_OK;
+}
+
+template <typename scalar_t, bool FP8, int HS, int BS>
+static int launch_mfma(const PagedAttnParams& p) {
+  switch (pa_variant()) {
+    // bit 1 (two register sets in flight) measured 1% slower than bit 0 alone on
+    // configs[1] (profiles/r01_ab_attention.txt) and is not instantiated
+    case 0: case 2: return launch_mfma_v<scalar_t, FP8, HS, BS, 0>(p);
+    default: return launch_mfma_v<scalar_t, FP8, HS, BS, 1>(p);
+  }
 }
 
 template <typename scalar_t>
@@ -455,7 +510,26 @@ static int dispatch_mfma(const PagedAttnParams& p) {
   VA_REQUIRE(false, VLLM_AMD_EUNSUPPORTED, "paged_attention mfma: unsupported shape");
 }
 
-int paged_attention_mfma(const PagedAttnParams& p) {
+// Super-partitions: the reference cuts every sequence into 512- (v2) or 256-token (rocm)
+// partitions, one workgroup each.  A 128 KiB workgroup is all prologue and merge on this
+// chip (5.4 TB/s); the same kernel with ~1 MiB per workgroup streams at 6.4-6.5 TB/s
+// (profiles/r01_ab_attention.txt).  So a workgroup takes `sp` consecutive reference
+// partitions, chosen so the launch has ~512 workgroups (one round of 2 per CU), writes ONE
+// partial into the first of its scratch slots, and the reduce kernel visits every sp-th
+// slot.  The scratch tensors are caller-allocated temporaries of the reference's shape;
+// only the slots we read are written.
+int paged_attention_mfma(const PagedAttnParams& p0) {
+  PagedAttnParams p = p0;
+  p.sp_parts = 1;
+  if (p.partition_size > 0) {
+    const int chunks = ceil_div(p.num_heads / p.num_kv_heads, 16);
+    const int64_t total = (int64_t)p.num_seqs * p.num_kv_heads * chunks * p.max_num_partitions;
+    int64_t sp = (total + 511) / 512;   // one round of 2 workgroups per CU
+    if (g_pa_sp > 0) sp = g_pa_sp;
+    if (sp < 1) sp = 1;
+    if (sp > p.max_num_partitions) sp = p.max_num_partitions;
+    p.sp_parts = (int)sp;
+  }
   if (p.dtype == VLLM_AMD_F16) return dispatch_mfma<f16_t>(p);
   return dispatch_mfma<bf16_t>(p);
 }
