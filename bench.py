@@ -101,6 +101,32 @@ def time_gpu(fn, steps, warmup, dist=None):
     return t1 - t0, e0.elapsed_time(e1) * 1e-3
 
 
+def time_gpu_graph(fn, iters, replays=5):
+    """Per-call device time of a short op: `iters` calls captured in one HIP graph and
+    replayed, so the host launch path (~15 us per eager call) is not what is measured."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / (iters * replays)
+
+
 def run_attention(cfg, steps, warmup, device, dist=None, version="auto"):
     from vllm_amd import _custom_ops as ops
     from vllm_amd.attention.paged_attn import PagedAttention
@@ -131,9 +157,10 @@ def run_scaled_mm(device, shapes, Ms, iters=20):
         for M in Ms:
             a = torch.randn((M, K), device=device, dtype=torch.bfloat16)
             aq, as_ = ops.scaled_fp8_quant(a, use_per_token_if_dynamic=True)
-            fn = lambda: ops.cutlass_scaled_mm(aq, wq.t(), as_, ws, torch.bfloat16)
-            _, ev = time_gpu(fn, iters, 3)
-            t = ev / iters
+            out = torch.empty((M, N), dtype=torch.bfloat16, device=device)
+            wt = wq.t()
+            fn = lambda: torch.ops._C.cutlass_scaled_mm(out, aq, wt, as_, ws, None)
+            t = time_gpu_graph(fn, iters)
             flops = 2.0 * M * N * K
             nbytes = M * K + K * N + 2 * M * N + 4 * (M + N)
             bound = min(FP8_DENSE_PEAK_TFLOPS, HBM_PEAK_GBPS * 1e9 * (flops / nbytes) / 1e12)
@@ -157,17 +184,19 @@ def run_cache_quant(device, iters=20):
         slots = torch.randperm(NB * BS, device=device)[:T].to(torch.int64)
         sc = torch.tensor([0.05], device=device)
         fn = lambda: ops.reshape_and_cache(k, v, kc, vc, slots, "fp8", sc, sc)
-        _, ev = time_gpu(fn, iters, 3)
+        t = time_gpu_graph(fn, iters)
         nbytes = T * KVH * D * (2 * 2 + 2 * 1) + 8 * T
-        out["reshape_and_cache_fp8_" + name] = dict(us=round(ev / iters * 1e6, 2),
-                                                    gbps=round(nbytes / (ev / iters) / 1e9, 1))
+        out["reshape_and_cache_fp8_" + name] = dict(us=round(t * 1e6, 2),
+                                                    gbps=round(nbytes / t / 1e9, 1))
     for M, K in ((64, 4096), (4096, 4096), (4096, 14336)):
         x = torch.randn((M, K), device=device, dtype=torch.bfloat16)
-        fn = lambda: ops.scaled_fp8_quant(x, use_per_token_if_dynamic=True)
-        _, ev = time_gpu(fn, iters, 3)
+        q = torch.empty((M, K), dtype=torch.float8_e4m3fn, device=device)
+        sc_ = torch.empty((M, 1), dtype=torch.float32, device=device)
+        fn = lambda: torch.ops._C.dynamic_per_token_scaled_fp8_quant(q, x, sc_, None)
+        t = time_gpu_graph(fn, iters)
         nbytes = M * K * 3 + 4 * M
-        out[f"per_token_quant_M{M}_K{K}"] = dict(us=round(ev / iters * 1e6, 2),
-                                                 gbps=round(nbytes / (ev / iters) / 1e9, 1))
+        out[f"per_token_quant_M{M}_K{K}"] = dict(us=round(t * 1e6, 2),
+                                                 gbps=round(nbytes / t / 1e9, 1))
     return out
 
 

@@ -91,6 +91,46 @@ __global__ __launch_bounds__(256) void rd_paged(const unsigned char* __restrict_
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
 }
 
+// skinny-GEMM weight stream candidates: W[N][K] bytes, a workgroup of 8 waves owns 16 rows,
+// wave w the K range [w*K/8, (w+1)*K/8).
+//  mode 0: MFMA-operand order straight to VGPRs: lane (r = lane&15, g = lane>>4) reads 16 B at
+//          row r, k = 64*i + 16*g  (16 rows x 64 B contiguous per instruction)
+//  mode 1: coalesced order: lanes 0-15 read 256 contiguous bytes of one row, 4 rows per instruction
+template <int MODE, bool NT>
+__global__ __launch_bounds__(512) void rd_rows16(const unsigned char* __restrict__ w, int K, unsigned* sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t row0 = (size_t)blockIdx.x * 16;
+  const int kw = K / 8;  // bytes per wave per row
+  u32x4 acc = {0, 0, 0, 0};
+  if (MODE == 0) {
+    const int r = lane & 15, g = lane >> 4;
+    const unsigned char* base = w + (row0 + r) * K + wave * kw + 16 * g;
+    for (int k = 0; k < kw; k += 512) {
+      u32x4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const u32x4* p = (const u32x4*)(base + k + 64 * i);
+        v[i] = NT ? __builtin_nontemporal_load(p) : *p;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc ^= v[i];
+    }
+  } else {
+    const int c = lane & 15, rr = lane >> 4;
+    for (int k = 0; k < kw; k += 256) {
+      u32x4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4* p = (const u32x4*)(w + (row0 + 4 * i + rr) * K + wave * kw + k + 16 * c);
+        v[i] = NT ? __builtin_nontemporal_load(p) : *p;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc ^= v[i];
+    }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 template <typename F> float timeit(F f, int iters) {
@@ -121,6 +161,22 @@ int main() {
         }
       }, 20);
       printf("linear wgs=%d nt=%d: %.1f us (2 launches) -> %.0f GB/s\n", wgs, nt, us, bytes / us / 1e3);
+    }
+  }
+  {
+    // skinny GEMM weight stream: two 256 MiB weight matrices alternated, K = 4096 and 14336
+    for (int K : {4096, 14336}) {
+      const int N = (int)((bytes / 2) / K / 16 * 16);
+      for (int mode = 0; mode < 2; ++mode) for (int nt = 0; nt < 2; ++nt) {
+        float us = timeit([&](int it) {
+          const unsigned char* wp = bufs[(it & 1) * 2];
+          if (mode == 0 && nt == 0) hipLaunchKernelGGL((rd_rows16<0, false>), dim3(N / 16), dim3(512), 0, 0, wp, K, sink);
+          if (mode == 0 && nt == 1) hipLaunchKernelGGL((rd_rows16<0, true>), dim3(N / 16), dim3(512), 0, 0, wp, K, sink);
+          if (mode == 1 && nt == 0) hipLaunchKernelGGL((rd_rows16<1, false>), dim3(N / 16), dim3(512), 0, 0, wp, K, sink);
+          if (mode == 1 && nt == 1) hipLaunchKernelGGL((rd_rows16<1, true>), dim3(N / 16), dim3(512), 0, 0, wp, K, sink);
+        }, 20);
+        printf("rows16 K=%d N=%d mode=%d nt=%d: %.1f us -> %.0f GB/s\n", K, N, mode, nt, us, (double)N * K / us / 1e3);
+      }
     }
   }
   // paged: S=64 seqs x 256 blocks, 8 heads, fp8 page 2 KiB (block = 16 KiB), bf16 page 4 KiB

@@ -169,6 +169,103 @@ __global__ __launch_bounds__(GEMM_THREADS) void scaled_mm_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Skinny GEMM, M <= 64 (decode): weight-bandwidth bound.  A workgroup of 8 waves
+// owns 16 weight rows (output columns) and ALL M rows; the waves split K.  W is
+// streamed once, straight into VGPRs in MFMA operand order (no LDS round trip:
+// each byte is used by one wave only); the contraction index inside a 128-byte
+// K block is permuted (lane group g takes bytes 64 j + 16 g, j = 0,1) so that one
+// load instruction reads 16 rows x 64 contiguous bytes -- A is loaded with the
+// same permutation, so the product is unchanged.  Partial sums of the 8 waves
+// are combined through LDS, then scales / cast / bias as in the tile kernel.
+// ---------------------------------------------------------------------------
+constexpr int SK_WAVES = 8;
+
+template <typename out_t, int MT>
+__global__ __launch_bounds__(SK_WAVES * 64) void scaled_mm_skinny_kernel(
+    out_t* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+    const float* __restrict__ a_scales, const float* __restrict__ b_scales,
+    const out_t* __restrict__ bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+    int a_scale_numel, int b_scale_numel) {
+  __shared__ float red[SK_WAVES][MT][16][17];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int nkb = (K + 127) / 128;                       // 128-byte K blocks
+  const int per = (nkb + SK_WAVES - 1) / SK_WAVES;
+  const int kb0 = wave * per, kb1 = min(kb0 + per, nkb);
+
+  const int n = n0 + c16;
+  const bool n_ok = n < N;
+  const uint8_t* wrow = b + (int64_t)(n_ok ? n : 0) * ldb + 16 * g4;
+  const uint8_t* arow[MT];
+  bool m_ok[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = t * 16 + c16;
+    m_ok[t] = m < M;
+    arow[t] = a + (int64_t)(m_ok[t] ? m : 0) * lda + 16 * g4;
+  }
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+  constexpr int UN = 4;  // K blocks in flight per wave
+  for (int kb = kb0; kb < kb1; kb += UN) {
+    uint4 wv[UN][2];
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = (kb + u) * 128 + 64 * j;            // + 16 g4 is in the row pointer
+        const bool ok = n_ok && (kb + u) < kb1 && (k + 16 * g4) < K;
+        const uint4 v = *reinterpret_cast<const uint4*>(wrow + (ok ? k : 0));   // unconditional
+        wv[u][j] = ok ? v : z4;
+      }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const i32x8 wf = (i32x8){(int)wv[u][0].x, (int)wv[u][0].y, (int)wv[u][0].z, (int)wv[u][0].w,
+                               (int)wv[u][1].x, (int)wv[u][1].y, (int)wv[u][1].z, (int)wv[u][1].w};
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        uint4 av[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int k = (kb + u) * 128 + 64 * j;
+          const bool ok = m_ok[t] && (kb + u) < kb1 && (k + 16 * g4) < K;
+          const uint4 v = *reinterpret_cast<const uint4*>(arow[t] + (ok ? k : 0));
+          av[j] = ok ? v : z4;
+        }
+        const i32x8 af = (i32x8){(int)av[0].x, (int)av[0].y, (int)av[0].z, (int)av[0].w,
+                                 (int)av[1].x, (int)av[1].y, (int)av[1].z, (int)av[1].w};
+        acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, af, acc[t], 0, 0, 0,
+                                                                  0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
+    }
+  }
+  // lane holds C^T[n = 4 g4 + r][m = 16 t + c16]
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][t][c16][4 * g4 + r] = acc[t][r];   // [m][n]
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < MT * 256; idx += SK_WAVES * 64) {
+    const int t = idx >> 8, mm = (idx >> 4) & 15, nn = idx & 15;
+    const int m = t * 16 + mm, no = n0 + nn;
+    if (m >= M || no >= N) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) v += red[w][t][mm][nn];
+    out_t o = finish<out_t>(v, a_scales[a_scale_numel == 1 ? 0 : m],
+                            b_scales[b_scale_numel == 1 ? 0 : no]);
+    if (bias) o = from_f32<out_t>(to_f32(o) + to_f32(bias[no]));
+    out[(int64_t)m * ldc + no] = o;
+  }
+}
+
 }  // namespace va
 
 using namespace va;
@@ -188,6 +285,24 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
              op);
   VA_REQUIRE((a_scale_numel == 1 || a_scale_numel == M) && (b_scale_numel == 1 || b_scale_numel == N),
              VLLM_AMD_EINVAL, "%s: scales must be per-tensor or per-row/per-column", op);
+  if (M <= 32) {
+    const int mt = ceil_div(M, 16);
+#define SK(T, MT)                                                                              \
+  hipLaunchKernelGGL((scaled_mm_skinny_kernel<T, MT>), dim3(ceil_div(N, 16)),                  \
+                     dim3(SK_WAVES * 64), 0, st, (T*)out, (const uint8_t*)a, (const uint8_t*)b, \
+                     a_scales, b_scales, (const T*)bias, M, N, K, lda, ldb, ldc, a_scale_numel, \
+                     b_scale_numel)
+#define SKT(T)                                       \
+  do {                                               \
+    if (mt == 1) SK(T, 1); else if (mt == 2) SK(T, 2); \
+    else if (mt == 3) SK(T, 3); else SK(T, 4);       \
+  } while (0)
+    if (out_dtype == VLLM_AMD_BF16) SKT(bf16_t); else SKT(f16_t);
+#undef SKT
+#undef SK
+    VA_LAUNCH_CHECK(op);
+    return VLLM_AMD_OK;
+  }
   const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
   const bool vec = (ldc % 4 == 0) && ((((uintptr_t)out) & 7) == 0);
 #define MM(T, V)                                                                              \
