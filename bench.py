@@ -285,6 +285,11 @@ def main():
     per_launch = ev / args.steps
     achieved = r["bytes"] / per_launch / 1e9
 
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_attention_pmc.json")
+    if os.path.exists(pmc):   # HBM bytes per launch from committed rocprofv3 PMC passes
+        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+
     line = {
         "metric": "paged-attn decode HBM GB/s (% peak) + fp8 scaled_mm TFLOPS at 1/2/4/8 GPUs",
         "value": round(value, 1),
@@ -305,7 +310,7 @@ def main():
                    "parallelism": f"kv-head sharded x{world}, no collective"},
         "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBPS, 2),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "kernel": "pa_mfma_kernel<bf16, fp8, 128, 16>",
                      "us_per_launch": round(per_launch * 1e6, 2),
                      "algorithmic_bytes_per_launch": r["bytes"]},

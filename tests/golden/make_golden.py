@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.pt (inputs + expected outputs).  Run in the authoring
+container (needs oracle/_ref/librefcpu.so built from /root/reference by oracle/Makefile):
+
+    python tests/golden/make_golden.py
+
+Sources of the expected outputs
+  attn_ref_*.pt     the reference's OWN CPU kernels (csrc/cpu/attention.cpp via oracle/_ref):
+                    paged_attention_v1 and _v2, bf16 / fp16 / fp32, block 16, with and without alibi
+  cache_ref_*.pt    the reference's own CPU reshape_and_cache (csrc/cpu/cache.cpp via oracle/_ref)
+  fp8_quant_*.pt    torch CPU restatement of the formulas in the reference's test helpers
+                    (tests/kernels/quant_utils.py:22-97: ref_dynamic_per_token_quant,
+                    ref_dynamic_per_tensor_fp8_quant) using torch.float8_e4m3fn casts
+  scaled_mm_*.pt    torch CPU restatement of baseline_scaled_mm (tests/kernels/utils.py:1212-1251)
+  fp8_codec.pt      all 256 e4m3fn codes decoded by torch + an encode sweep by torch casts
+The fixtures are DATA only; nothing of the reference's source text is stored.
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle as O  # noqa: E402
+from helpers import make_attn_case  # noqa: E402
+
+FP8_MAX = 448.0
+
+
+def save(name, d):
+    torch.save(d, os.path.join(HERE, name))
+    print(name, sum(v.numel() * v.element_size() for v in d.values() if torch.is_tensor(v)) // 1024, "KiB")
+
+
+def attention():
+    assert O.load_ref(), "build oracle/_ref first (make -C oracle ref)"
+    one = torch.ones(1)
+    for dtype, tag in ((torch.bfloat16, "bf16"), (torch.float16, "fp16"), (torch.float32, "fp32")):
+        for H, KVH in (((4, 2), (4, 1)) if tag != "fp32" else ((4, 1),)):
+            lens = [1, 16, 17, 130, 513]
+            c = make_attn_case(len(lens), H, KVH, 128, 16, dtype, "auto", lens, seed=H + KVH,
+                               alibi=(KVH == 1), num_blocks=48)
+            out1 = torch.empty_like(c["q"])
+            torch.ops.refcpu.paged_attention_v1(out1, c["q"], c["kc"], c["vc"], KVH, c["scale"],
+                                                c["bt"], c["sl"], 16, c["max_len"], c["slopes"],
+                                                "auto", one, one, 0, 0, 0, 64, 0)
+            P = (c["max_len"] + 511) // 512
+            S, _, D = c["q"].shape
+            es = torch.zeros((S, H, P)); ml = torch.zeros_like(es)
+            tmp = torch.zeros((S, H, P, D), dtype=dtype)
+            out2 = torch.empty_like(c["q"])
+            torch.ops.refcpu.paged_attention_v2(out2, es, ml, tmp, c["q"], c["kc"], c["vc"], KVH,
+                                                c["scale"], c["bt"], c["sl"], 16, c["max_len"],
+                                                c["slopes"], "auto", one, one, 0, 0, 0, 64, 0)
+            d = dict(q=c["q"], kc=c["kc"], vc=c["vc"], bt=c["bt"], sl=c["sl"], out_v1=out1,
+                     out_v2=out2, scale=torch.tensor(c["scale"]), num_kv_heads=torch.tensor(KVH))
+            if c["slopes"] is not None:
+                d["slopes"] = c["slopes"]
+            save(f"attn_ref_{tag}_h{H}kv{KVH}.pt", d)
+
+
+def cache():
+    assert O.load_ref()
+    one = torch.ones(1)
+    for dtype, tag in ((torch.bfloat16, "bf16"), (torch.float16, "fp16"), (torch.float32, "fp32")):
+        g = torch.Generator().manual_seed(11)
+        T, H, D, BS, NB = 23, 4, 64, 16, 12
+        x = 16 // torch.tensor([], dtype=dtype).element_size()
+        key = torch.randn((T, H, D), generator=g).to(dtype)
+        value = torch.randn((T, H, D), generator=g).to(dtype)
+        slots = torch.randperm(NB * BS, generator=g)[:T].to(torch.int64)
+        kc = torch.zeros((NB, H, D // x, BS, x), dtype=dtype)
+        vc = torch.zeros((NB, H, D, BS), dtype=dtype)
+        torch.ops.refcpu.reshape_and_cache(key, value, kc, vc, slots, "auto", one, one)
+        save(f"cache_ref_{tag}.pt", dict(key=key, value=value, slots=slots, kc=kc, vc=vc))
+
+
+def fp8_quant():
+    g = torch.Generator().manual_seed(5)
+    min_scale = 1.0 / (FP8_MAX * 512.0)
+    for dtype, tag in ((torch.bfloat16, "bf16"), (torch.float16, "fp16"), (torch.float32, "fp32")):
+        x = (torch.rand((9, 1031), generator=g) * 1000 + 1e-6).to(dtype)
+        xf = x.float()
+        # per token (quant_utils.py:22-61): scale = max(amax / 448, 1/(448*512)); q = sat(x / scale)
+        amax = xf.abs().amax(dim=-1, keepdim=True)
+        ub = torch.tensor([amax.mean().item()])
+        out = {}
+        for name, am in (("pt", amax), ("ptub", amax.clamp(max=ub))):
+            s = (am / FP8_MAX).clamp(min=min_scale)
+            q = (xf / s).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+            out[name + "_q"] = q
+            out[name + "_s"] = s
+        # per tensor (quant_utils.py:66-97): scale = amax / 448 ; q = sat(x * (1 / scale))
+        s = (xf.abs().max() / FP8_MAX).reshape(1)
+        q = (xf * (1.0 / s)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+        out.update(x=x, ub=ub, tensor_q=q, tensor_s=s)
+        save(f"fp8_quant_{tag}.pt", out)
+
+
+def scaled_mm():
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 33, 200, 496
+    a = torch.randn((M, K), generator=g).to(torch.float8_e4m3fn)
+    w = torch.randn((N, K), generator=g).to(torch.float8_e4m3fn)
+    sa = torch.rand((M, 1), generator=g) * 0.05 + 0.01
+    sb = torch.rand((N, 1), generator=g) * 0.05 + 0.01
+    bias = torch.randn(N, generator=g).to(torch.bfloat16)
+    # baseline_scaled_mm: (scale_a * a.f32) @ (scale_b * b.f32) -> out dtype (+ bias)
+    ref = torch.mm(sa * a.float(), (sb * w.float()).t())
+    save("scaled_mm_bf16.pt", dict(a=a.view(torch.uint8), w=w.view(torch.uint8), sa=sa, sb=sb,
+                                   bias=bias, out=ref.to(torch.bfloat16),
+                                   out_bias=(ref + bias.float()).to(torch.bfloat16)))
+
+
+def fp8_codec():
+    codes = torch.arange(256, dtype=torch.uint8)
+    dec = codes.view(torch.float8_e4m3fn).float()
+    fin = dec[~dec.isnan()].sort().values
+    mids = (fin[:-1] + fin[1:]) / 2
+    g = torch.Generator().manual_seed(1)
+    x = torch.cat([fin, mids, mids * (1 + 2 ** -12), mids * (1 - 2 ** -12),
+                   torch.randn(4096, generator=g) * 50, torch.randn(4096, generator=g) * 0.01,
+                   torch.tensor([449.0, 1e6, -1e6, 464.0, 465.0, -464.0])])
+    enc = x.clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+    save("fp8_codec.pt", dict(dec=dec, x=x, enc=enc))
+
+
+if __name__ == "__main__":
+    attention(); cache(); fp8_quant(); scaled_mm(); fp8_codec()

@@ -1,0 +1,127 @@
+"""CPU tests (no GPU): the C-ABI library loads, exports every symbol declared in
+include/vllm_amd.h, the torch ops carry the reference's schema strings, and argument
+validation returns the reference's error text BEFORE anything is launched."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vllm_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vllm_amd_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vllm_amd import _lib
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(_lib.lib, s), f"{s} declared in include/vllm_amd.h but not exported"
+    # and the ctypes signatures cover every entry point that takes arguments
+    for s in syms:
+        if s not in ("vllm_amd_last_error", "vllm_amd_version"):
+            assert s in _lib.SIGNATURES, s
+    assert _lib.lib.vllm_amd_version() >= 100
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    import importlib.util
+    src = os.path.join(ROOT, "vllm_amd", "_lib.py")
+    spec = importlib.util.spec_from_file_location("lib_probe", src)
+    mod = importlib.util.module_from_spec(spec)
+    monkeypatch.setattr(os.path, "exists", lambda p: False if p.endswith("libvllm_amd.so") else True)
+    with pytest.raises(ImportError, match="no CPU or\\s+eager fallback|not built"):
+        spec.loader.exec_module(mod)
+
+
+SCHEMAS = {
+    # SURVEY.md 8b, verbatim from csrc/torch_bindings.cpp / csrc/rocm/torch_bindings.cpp
+    "_C::paged_attention_v1": "(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, int num_kv_heads, float scale, Tensor block_tables, Tensor seq_lens, int block_size, int max_seq_len, Tensor? alibi_slopes, str kv_cache_dtype, Tensor k_scale, Tensor v_scale, int tp_rank, int blocksparse_local_blocks, int blocksparse_vert_stride, int blocksparse_block_size, int blocksparse_head_sliding_step) -> ()",
+    "_C::static_scaled_fp8_quant": "(Tensor! result, Tensor input, Tensor scale) -> ()",
+    "_C::dynamic_per_token_scaled_fp8_quant": "(Tensor! result, Tensor input, Tensor! scale, Tensor? scale_ub) -> ()",
+    "_C::cutlass_scaled_mm": "(Tensor! out, Tensor a, Tensor b, Tensor a_scales, Tensor b_scales, Tensor? bias) -> ()",
+    "_C_cache_ops::reshape_and_cache": "(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, Tensor slot_mapping, str kv_cache_dtype, Tensor k_scale, Tensor v_scale) -> ()",
+    "_C_cache_ops::convert_fp8": "(Tensor! dst_cache, Tensor src_cache, float scale, str kv_cache_dtype) -> ()",
+    "_rocm_C::wvSplitKQ": "(Tensor in_a, Tensor in_b, Tensor! out_c, Tensor scale_a, Tensor scale_b, int CuCount) -> ()",
+}
+
+
+def test_torch_ops_registered_with_reference_schemas():
+    import vllm_amd._custom_ops  # noqa: F401
+    for name, want in SCHEMAS.items():
+        ns, op = name.split("::")
+        schema = getattr(getattr(torch.ops, ns), op).default._schema
+        assert str(schema) == str(torch._C.parse_schema(name + want)), str(schema)
+    for ns, op in (("_C", "paged_attention_v2"), ("_rocm_C", "paged_attention"),
+                   ("_C_cache_ops", "reshape_and_cache_flash"), ("_C_cache_ops", "copy_blocks"),
+                   ("_C_cache_ops", "swap_blocks"), ("_C", "dynamic_scaled_fp8_quant")):
+        assert hasattr(getattr(torch.ops, ns), op)
+
+
+def _err(rc):
+    from vllm_amd import _lib
+    assert rc != 0
+    return _lib.lib.vllm_amd_last_error().decode()
+
+
+def test_validation_errors_without_launch():
+    """Errors are decided on the host from shapes / enums only (dummy non-null pointers are
+    never dereferenced, nothing is launched): same messages as the reference's TORCH_CHECKs."""
+    from vllm_amd import _lib
+    L = _lib.lib
+    p = 0x1000  # aligned, never touched
+    def v1(head_size=128, block_size=16, dtype=_lib.BF16, kv=_lib.KV_AUTO, num_seqs=1, heads=8, kvh=8):
+        return L.vllm_amd_paged_attention_v1(p, p, p, p, num_seqs, heads, head_size, kvh, 1.0, p, p, 4,
+                                             block_size, 64, None, dtype, kv, p, p, heads * head_size,
+                                             kvh * head_size * block_size, head_size * block_size,
+                                             0, 0, 0, 64, 0, None)
+    assert "Unsupported head size: 100" in _err(v1(head_size=100))
+    assert "Unsupported block size: 24" in _err(v1(block_size=24))
+    assert "Unsupported data type of kv cache" in _err(v1(kv=7))
+    assert "Unsupported data type" in _err(v1(dtype=9))
+    assert "not divisible" in _err(v1(heads=8, kvh=3))
+    assert v1(num_seqs=0) == 0          # empty batch: nothing to do, no launch
+    # v2: scratch too small for max_seq_len
+    rc = L.vllm_amd_paged_attention_v2(p, p, p, p, p, p, p, 1, 8, 128, 8, 1.0, p, p, 4, 16, 4096, 2,
+                                       None, _lib.BF16, _lib.KV_AUTO, p, p, 1024, 16384, 2048,
+                                       0, 0, 0, 64, 0, None)
+    assert "max_num_partitions 2 too small" in _err(rc)
+    # rocm op: fp32 query is not accepted (csrc/rocm/attention.cu:3494-3539)
+    rc = L.vllm_amd_paged_attention_rocm(p, p, p, p, p, p, p, 1, 8, 128, 8, 1.0, p, p, None, 4, 16,
+                                         64, 1, None, _lib.F32, _lib.KV_AUTO, p, p, None, 1024,
+                                         16384, 2048, None)
+    assert "Unsupported data type" in _err(rc)
+    # cache write
+    rc = L.vllm_amd_reshape_and_cache(p, p, p, p, p, 4, 8, 120, 16, 16, 960, 960, _lib.BF16,
+                                      _lib.KV_FP8_E4M3, p, p, None)
+    assert "not divisible by x" in _err(rc)
+    assert L.vllm_amd_reshape_and_cache(p, p, p, p, p, 0, 8, 128, 16, 8, 1024, 1024, _lib.BF16,
+                                        _lib.KV_AUTO, None, None, None) == 0
+    # quant / gemm
+    assert L.vllm_amd_static_scaled_fp8_quant(p, p, p, 0, 128, _lib.BF16, None) == 0
+    assert "unsupported dtype" in _err(L.vllm_amd_static_scaled_fp8_quant(p, p, p, 4, 128, 9, None))
+    rc = L.vllm_amd_scaled_mm(p, p, p, p, p, None, 4, 8, 100, 100, 100, 8, 1, 1, _lib.BF16, None)
+    assert "multiples of 16" in _err(rc)
+    rc = L.vllm_amd_scaled_mm(p, p, p, p, p, None, 4, 8, 128, 128, 128, 8, 1, 1, _lib.F32, None)
+    assert "bfloat16 or float16" in _err(rc)
+    rc = L.vllm_amd_scaled_mm(p, p, p, p, p, None, 4, 8, 128, 128, 128, 8, 3, 1, _lib.BF16, None)
+    assert "per-tensor or per-row" in _err(rc)
+    assert "batch 5 > 4" in _err(L.vllm_amd_wvSplitKQ(p, p, p, p, p, 64, 128, 5, _lib.BF16, 256, None))
+    assert "unknown key" in _err(L.vllm_amd_set_tuning(b"nope", 1))
+
+
+def test_torch_layer_rejects_cpu_tensors_and_bad_strings():
+    from vllm_amd import _custom_ops as ops, _torch_ops
+    x = torch.zeros((2, 16), dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="device tensors"):
+        _torch_ops.static_scaled_fp8_quant(torch.zeros((2, 16), dtype=torch.float8_e4m3fn), x,
+                                           torch.ones(1))
+    with pytest.raises(RuntimeError, match="Unsupported data type of kv cache: fp8_e5m2"):
+        _torch_ops._kv("fp8_e5m2")
+    assert ops.FP8_DTYPE == torch.float8_e4m3fn
