@@ -84,3 +84,54 @@ def test_wvSplitKQ(ops, oracle, n, mk):
     assert out.shape == (n, m)
     ref = oracle.scaled_mm(A.view(torch.uint8), B.view(torch.uint8).t(), sa, sb, torch.bfloat16)
     torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=1e-2, atol=1e-3)
+
+
+@pytest.fixture
+def force_kernel():
+    """Pin the GEMM kernel choice (vllm_amd_set_tuning "mm_kernel"); back to auto afterwards."""
+    from vllm_amd import _lib
+    yield lambda k: _lib.set_tuning("mm_kernel", k)
+    _lib.set_tuning("mm_kernel", 0)
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("MNK", [(300, 520, 256), (256, 256, 1024), (257, 971, 384), (640, 1288, 2048),
+                                 (40, 8, 128 * 3)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
+def test_scaled_mm_every_tile_kernel(ops, oracle, force_kernel, kernel, MNK, out_dtype):
+    """The auto dispatch picks the 128x256 / 256x256 direct-to-LDS kernels only for large
+    problems; force each one on ragged small shapes (edge tiles, odd N -> scalar epilogue,
+    odd number of K blocks, bias) so the oracle still finishes in seconds."""
+    M, N, K = MNK
+    force_kernel(kernel)
+    check(ops, oracle, M, N, K, True, True, out_dtype, bias=(N % 2 == 0), seed=M + N + K + kernel)
+    check(ops, oracle, M, N, K, False, False, out_dtype, bias=False, seed=M + N + kernel)
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+def test_scaled_mm_integer_exact_every_kernel(ops, force_kernel, kernel):
+    M, N, K = 512, 768, 640
+    g = torch.Generator().manual_seed(kernel)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    a[:, 0] = torch.arange(M).float() % 7
+    w[:, 1] = torch.arange(N).float() % 5
+    one = torch.ones((1, 1))
+    force_kernel(kernel)
+    out = ops.cutlass_scaled_mm(a.to(torch.float8_e4m3fn).cuda(), w.to(torch.float8_e4m3fn).cuda().t(),
+                                one.cuda(), one.cuda(), torch.float16)
+    assert torch.equal(out.cpu().float(), (a @ w.t()).to(torch.float16).float())
+
+
+def test_scaled_mm_large_auto(ops):
+    """Full-size shape on the auto-dispatched large kernel, checked through a size-independent
+    property instead of the oracle: with power-of-two operands every product and partial
+    sum is exact, so out == K * sa * sb * pattern regardless of summation order."""
+    M, N, K = 4096, 4096, 4096
+    a = torch.full((M, K), 0.5).to(torch.float8_e4m3fn).cuda()
+    w = torch.full((N, K), 2.0).to(torch.float8_e4m3fn).cuda()
+    sa = (2.0 ** -(torch.arange(M) % 5).float()).reshape(M, 1).cuda()
+    sb = (2.0 ** -(torch.arange(N) % 3).float()).reshape(N, 1).cuda()
+    out = ops.cutlass_scaled_mm(a, w.t(), sa, sb, torch.bfloat16)
+    ref = (K * sa * sb.t()).to(torch.bfloat16)
+    assert torch.equal(out, ref)

@@ -9,7 +9,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--ms", default="1,16,64,128,256,512,1024,4096")
 ap.add_argument("--shapes", default="4096x6144,4096x4096,4096x28672,14336x4096")
 ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--mm-kernel", type=int, default=0, help="0 auto, 1 = 128x128, 2 = 128x256 glds, 3 = 256x256 glds")
 a = ap.parse_args()
+if a.mm_kernel:
+    from vllm_amd import _lib
+    _lib.set_tuning("mm_kernel", a.mm_kernel)
 shapes = [tuple(int(x) for x in s.split("x")) for s in a.shapes.split(",")]
 res = bench.run_scaled_mm(torch.device("cuda", 0), shapes, [int(m) for m in a.ms.split(",")], a.iters)
 for r in res:

@@ -24,6 +24,8 @@
 
 namespace va {
 
+extern int g_mm_kernel;
+
 template <typename cache_t> struct CacheTraits;
 template <> struct CacheTraits<float> { static constexpr int X = 4; };
 template <> struct CacheTraits<f16_t> { static constexpr int X = 8; };
@@ -515,5 +517,6 @@ extern "C" int vllm_amd_set_tuning(const char* key, int value) {
   VA_REQUIRE(key != nullptr, VLLM_AMD_EINVAL, "set_tuning: null key");
   if (strcmp(key, "pa_variant") == 0) { set_pa_variant(value); return VLLM_AMD_OK; }
   if (strcmp(key, "pa_sp") == 0) { set_pa_sp(value); return VLLM_AMD_OK; }
+  if (strcmp(key, "mm_kernel") == 0) { g_mm_kernel = value; return VLLM_AMD_OK; }
   VA_REQUIRE(false, VLLM_AMD_EINVAL, "set_tuning: unknown key %s", key);
 }

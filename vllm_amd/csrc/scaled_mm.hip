@@ -266,6 +266,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void scaled_mm_skinny_kernel(
   }
 }
 
+// scaled_mm_large.hip
+void launch_scaled_mm_large(int bm, void* out, const void* a, const void* b,
+                            const float* a_scales, const float* b_scales, const void* bias, int M,
+                            int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int asn, int bsn,
+                            int out_dtype, bool vec, hipStream_t st);
+bool scaled_mm_large_fits(int M, int N, int K, int64_t lda, int64_t ldb);
+int g_mm_kernel = 0;   // tuning: 0 auto, 1 = 128x128 tile, 2 = 128x256 glds, 3 = 256x256 glds
 }  // namespace va
 
 using namespace va;
@@ -305,6 +312,22 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
   }
   const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
   const bool vec = (ldc % 4 == 0) && ((((uintptr_t)out) & 7) == 0);
+  if (K % 128 == 0 && K >= 256 && scaled_mm_large_fits(M, N, K, lda, ldb)) {
+    int sel = g_mm_kernel;
+    if (sel == 0) {
+      const int t256 = ceil_div(M, 256) * ceil_div(N, 256);
+      const int t128 = ceil_div(M, 128) * ceil_div(N, 256);
+      sel = t256 >= 192 ? 3 : (t128 >= 128 ? 2 : 1);
+    }
+    if (sel >= 2) {
+      // 16-byte row-contiguous stores through LDS
+      const bool vec16 = ldc % 8 == 0 && N % 8 == 0 && ((((uintptr_t)out) & 15) == 0);
+      launch_scaled_mm_large(sel == 3 ? 256 : 128, out, a, b, a_scales, b_scales, bias, M, N, K,
+                             lda, ldb, ldc, a_scale_numel, b_scale_numel, out_dtype, vec16, st);
+      VA_LAUNCH_CHECK(op);
+      return VLLM_AMD_OK;
+    }
+  }
 #define MM(T, V)                                                                              \
   hipLaunchKernelGGL((scaled_mm_kernel<T, V>), dim3(tiles), dim3(GEMM_THREADS), 0, st, (T*)out, \
                      (const uint8_t*)a, (const uint8_t*)b, a_scales, b_scales, (const T*)bias, \
