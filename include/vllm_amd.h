@@ -206,6 +206,10 @@ int vllm_amd_wvSplitKQ(const void* in_a, const void* in_b, void* out_c,
 /*                 registers in flight (not instantiated, measured slower)     */
 /*   "pa_sp":      reference partitions merged per workgroup in v2 / rocm      */
 /*                 launches (0 = heuristic, paged_attention_mfma.hip)          */
+/*   "mm_kernel":  scaled_mm kernel for M > 32: 0 = heuristic, 1 = register-   */
+/*                 staged 128x128 tile, 2..10 = direct-to-LDS tile shapes       */
+/*                 (256x256, 128x128, 128x64, 64x64, 64x32; even ids 4..10      */
+/*                 take 2 or 4 K blocks per barrier; scaled_mm_large.hip)       */
 /* ------------------------------------------------------------------------- */
 int vllm_amd_set_tuning(const char* key, int value);
 

@@ -94,13 +94,12 @@ def force_kernel():
     _lib.set_tuning("mm_kernel", 0)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("kernel", list(range(1, 11)))
 @pytest.mark.parametrize("MNK", [(300, 520, 256), (256, 256, 1024), (257, 971, 384), (640, 1288, 2048),
                                  (40, 8, 128 * 3)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
 def test_scaled_mm_every_tile_kernel(ops, oracle, force_kernel, kernel, MNK, out_dtype):
-    """The auto dispatch picks the 128x256 / 256x256 direct-to-LDS kernels only for large
-    problems; force each one on ragged small shapes (edge tiles, odd N -> scalar epilogue,
+    """The auto dispatch picks a tile shape from the problem size; force each one on ragged small shapes (edge tiles, odd N -> scalar epilogue,
     odd number of K blocks, bias) so the oracle still finishes in seconds."""
     M, N, K = MNK
     force_kernel(kernel)
@@ -108,7 +107,7 @@ def test_scaled_mm_every_tile_kernel(ops, oracle, force_kernel, kernel, MNK, out
     check(ops, oracle, M, N, K, False, False, out_dtype, bias=False, seed=M + N + kernel)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("kernel", list(range(1, 11)))
 def test_scaled_mm_integer_exact_every_kernel(ops, force_kernel, kernel):
     M, N, K = 512, 768, 640
     g = torch.Generator().manual_seed(kernel)

@@ -267,12 +267,12 @@ __global__ __launch_bounds__(SK_WAVES * 64) void scaled_mm_skinny_kernel(
 }
 
 // scaled_mm_large.hip
-void launch_scaled_mm_large(int bm, void* out, const void* a, const void* b,
+void launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
                             const float* a_scales, const float* b_scales, const void* bias, int M,
                             int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int asn, int bsn,
                             int out_dtype, bool vec, hipStream_t st);
 bool scaled_mm_large_fits(int M, int N, int K, int64_t lda, int64_t ldb);
-int g_mm_kernel = 0;   // tuning: 0 auto, 1 = 128x128 tile, 2 = 128x256 glds, 3 = 256x256 glds
+int g_mm_kernel = 0;   // tuning: 0 auto, 1 = register-staged 128x128, 2..10 = glds tile shapes
 }  // namespace va
 
 using namespace va;
@@ -315,14 +315,28 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
   if (K % 128 == 0 && K >= 256 && scaled_mm_large_fits(M, N, K, lda, ldb)) {
     int sel = g_mm_kernel;
     if (sel == 0) {
-      const int t256 = ceil_div(M, 256) * ceil_div(N, 256);
-      const int t128 = ceil_div(M, 128) * ceil_div(N, 256);
-      sel = t256 >= 192 ? 3 : (t128 >= 128 ? 2 : 1);
+      // Largest tile that still yields ~3/4 of a full wave of workgroups (256 CUs); rows of
+      // a tile beyond M are wasted MFMA work, so BM <= 2 M.  With >= 1.5 waves of tiles the
+      // variant that fits several workgroups per CU wins, below that the variant that takes
+      // KB K-blocks per barrier (measured: tools/sweep_gemm.py, profiles/r01_gemm_sweep.csv).
+      struct GldsTile { int id, id_kb, bm, bn, kb; };
+      static const GldsTile tiles_tab[5] = {{2, 2, 256, 256, 1}, {3, 4, 128, 128, 2},
+                                            {5, 6, 128, 64, 2},  {7, 8, 64, 64, 4},
+                                            {9, 10, 64, 32, 4}};
+      for (int i = 0; i < 5; ++i) {
+        const GldsTile& t = tiles_tab[i];
+        if (i < 4 && t.bm > 64 && M <= t.bm / 2) continue;
+        const int nt = ceil_div(M, t.bm) * ceil_div(N, t.bn);
+        if (nt >= 190 || i == 4) {
+          sel = (nt >= 384 || K % (128 * t.kb) != 0) ? t.id : t.id_kb;
+          break;
+        }
+      }
     }
     if (sel >= 2) {
       // 16-byte row-contiguous stores through LDS
       const bool vec16 = ldc % 8 == 0 && N % 8 == 0 && ((((uintptr_t)out) & 15) == 0);
-      launch_scaled_mm_large(sel == 3 ? 256 : 128, out, a, b, a_scales, b_scales, bias, M, N, K,
+      launch_scaled_mm_large(sel, out, a, b, a_scales, b_scales, bias, M, N, K,
                              lda, ldb, ldc, a_scale_numel, b_scale_numel, out_dtype, vec16, st);
       VA_LAUNCH_CHECK(op);
       return VLLM_AMD_OK;

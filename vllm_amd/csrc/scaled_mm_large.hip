@@ -1,26 +1,36 @@
-// Large-M fp8 scaled GEMM for gfx950: BM x 256 x 128B tiles, 8 waves, direct-to-LDS
-// staging (global_load_lds, 16 B per lane) with the NEXT K block in flight under the
-// MFMAs of the current one.
+// fp8 scaled GEMM for gfx950, M > 32: BM x BN x 128B tiles, direct-to-LDS staging
+// (global_load_lds, 16 B per lane) with the NEXT K block in flight under the MFMAs of the
+// current one.  One kernel template, several tile shapes (launch_glds_shape at the bottom):
+//   256x256 for MFMA-bound problems, 128x128 / 128x64 / 64x64 / 64x32 for the mid-M range
+//   where the point is to spread the weight stream over every CU; the small tiles also come
+//   in a variant that takes KB = 2 or 4 K blocks per barrier.
 //
 //   out[M,N] = ((sa (.) A[M,K]) . (sb (.) W[N,K]^T)).to(out_t) (+ bias)      K % 128 == 0
 //
 // Structure (cdna_hip_programming.md section 5, "glds, 2 LDS buffers"):
-//   * tile BM(M) x 256(N), K block = 128 bytes = one v_mfma_scale_f32_16x16x128_f8f6f4;
-//     8 waves as 2(M) x 4(N); a wave owns (BM/2) x 64 outputs = (BM/32) x 4 MFMA tiles;
+//   * K block = 128 bytes = one v_mfma_scale_f32_16x16x128_f8f6f4 (unit E8M0 scales: the
+//     only fp8 MFMA that runs at the 2x rate); waves as WM(M) x WN(N), a wave owns
+//     (BM/WM) x (BN/WN) outputs = MT x NT MFMA tiles;
 //   * the product is computed transposed (A operand = weight rows, B operand = activation
 //     rows) so a lane holds 4 consecutive n of one output row;
 //   * LDS image per operand and stage: [rows][128 B], 16-byte chunks XOR-swizzled by
 //     f(row) (same f as scaled_mm.hip: conflict-free ds_read_b128).  global_load_lds writes
 //     lane-linearly (wave base + 16*lane), so the swizzle is applied to the per-lane SOURCE
 //     address and to the read address -- never to the destination;
-//   * ONE barrier per K block:   wait own DMA of stage cur -> s_barrier -> issue DMA of
-//     block k+1 into stage cur^1 (everyone is past its reads of that stage) -> fragment
-//     reads + MFMAs of stage cur.  The DMA has a whole MFMA phase to land;
+//   * ONE barrier per K block (or per group of KB blocks): wait own DMA of the current
+//     buffer -> s_barrier -> issue the DMA that refills the buffer consumed last time
+//     (everyone is past its reads of it) -> fragment reads + MFMAs of the current buffer.
+//     A ring of NST buffers keeps NST-1 block groups in flight;
 //   * fragment reads are inline-asm ds_read_b128 with hand-counted lgkmcnt: with C++ LDS
 //     loads hipcc orders every ds_read behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)
 //     right after the barrier), which serialises the prefetch with the math.  The waits
-//     carry the fragment registers as in/out operands, so the MFMAs depend on them.
+//     carry the fragment registers as in/out operands, so the MFMAs depend on them;
+//   * stores go through LDS (the tile overlays the staging buffers) so that every store
+//     instruction writes whole rows of the tile: direct stores from the MFMA layout write
+//     32-byte pieces of 16 rows per instruction and cost 25 us on a 32 MB output.
 #include "common.cuh"
+#include <type_traits>
+#include <utility>
 
 namespace va {
 
@@ -28,7 +38,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
-constexpr int LBN = 256, LBK = 128, L_THREADS = 512;
+constexpr int LBK = 128;
 
 __device__ __forceinline__ int lswz(int row) {
   return ((row >> 1) & 1) | (((row >> 2) & 1) << 2);
@@ -41,29 +51,87 @@ __device__ __forceinline__ i32x4 lds_read16(uint32_t addr) {
   return v;
 }
 
+// fragment T (16 rows) of an operand, BASE bytes into the ring: two 16-byte halves at the
+// per-lane addresses a0/a1
+template <int BASE, int T>
+__device__ __forceinline__ void lds_read_frag(uint32_t a0, uint32_t a1, i32x4& lo, i32x4& hi) {
+  static_assert(BASE + T * 16 * LBK < 65536, "ds_read offset is 16 bits");
+  lo = lds_read16<BASE + T * 16 * LBK>(a0);
+  hi = lds_read16<BASE + T * 16 * LBK>(a1);
+}
+
+template <int BASE, int T0, int NT>
+__device__ __forceinline__ void read_w(uint32_t a0, uint32_t a1, i32x4 (&lo)[NT], i32x4 (&hi)[NT]) {
+  lds_read_frag<BASE, 0>(a0, a1, lo[0], hi[0]);
+  if constexpr (NT > 1) lds_read_frag<BASE, 1>(a0, a1, lo[1], hi[1]);
+  if constexpr (NT > 2) {
+    lds_read_frag<BASE, 2>(a0, a1, lo[2], hi[2]);
+    lds_read_frag<BASE, 3>(a0, a1, lo[3], hi[3]);
+  }
+}
+
+// s_waitcnt lgkmcnt(LATER) = "all LDS reads but the LATER youngest have returned".  The
+// fragments pass through the asm as in/out operands, so their consumers stay behind it.
+template <int LATER>
+__device__ __forceinline__ void wait_frag(i32x4& a0, i32x4& a1) {
+  asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(a0), "+v"(a1) : [n] "n"(LATER));
+}
+
+template <int LATER, int NT>
+__device__ __forceinline__ void wait_frags(i32x4 (&wl)[NT], i32x4 (&wh)[NT], i32x4& a0, i32x4& a1) {
+  static_assert(LATER <= 15, "lgkmcnt is 4 bits");
+  if constexpr (NT == 4)
+    asm volatile("s_waitcnt lgkmcnt(%[n])"
+                 : "+v"(wl[0]), "+v"(wh[0]), "+v"(wl[1]), "+v"(wh[1]), "+v"(wl[2]), "+v"(wh[2]),
+                   "+v"(wl[3]), "+v"(wh[3]), "+v"(a0), "+v"(a1)
+                 : [n] "n"(LATER));
+  else if constexpr (NT == 2)
+    asm volatile("s_waitcnt lgkmcnt(%[n])"
+                 : "+v"(wl[0]), "+v"(wh[0]), "+v"(wl[1]), "+v"(wh[1]), "+v"(a0), "+v"(a1)
+                 : [n] "n"(LATER));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(wl[0]), "+v"(wh[0]), "+v"(a0), "+v"(a1) : [n] "n"(LATER));
+}
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 __device__ __forceinline__ i32x8 cat8(i32x4 lo, i32x4 hi) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <typename out_t, int BM, bool VEC_STORE>
-__global__ __launch_bounds__(L_THREADS) void scaled_mm_large_kernel(
+template <typename out_t, int BM, int BN, int WM, int WN, int NST, int KB, bool VEC_STORE>
+__global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
     out_t* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ a_scales, const float* __restrict__ b_scales,
     const out_t* __restrict__ bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
     int a_scale_numel, int b_scale_numel) {
-  constexpr int A_BYTES = BM * LBK, W_BYTES = LBN * LBK, STAGE = A_BYTES + W_BYTES;
-  constexpr int MT = BM / 32;        // m tiles (16 rows) per wave
-  constexpr int A_ROUNDS = BM / 64;  // glds rounds: 8 waves x 8 rows per round
-  constexpr int W_ROUNDS = LBN / 64;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STAGE];
+  constexpr int NW = WM * WN;
+  constexpr int A_BYTES = BM * LBK, W_BYTES = BN * LBK, STAGE = A_BYTES + W_BYTES;
+  constexpr int MT = BM / WM / 16, NT = BN / WN / 16;   // MFMA tiles per wave
+  constexpr int RPR = 8 * NW;                            // rows staged per glds round
+  constexpr int A_ROUNDS = BM / RPR, W_ROUNDS = BN / RPR;
+  static_assert(BM % RPR == 0 && BN % RPR == 0, "tile rows must fill whole glds rounds");
+  static_assert(NT == 1 || NT == 2 || NT == 4, "");
+  static_assert(MT >= 1 && MT <= 8, "");
+  static_assert(NST >= 2 && NST * KB * STAGE <= 160 * 1024, "");
+  constexpr int LOADS = A_ROUNDS + W_ROUNDS;           // glds per lane and stage
+  static_assert((NST - 2) * KB * LOADS <= 63, "vmcnt is 6 bits");
+  __shared__ __attribute__((aligned(16))) uint8_t lds[NST * KB * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, g4 = lane >> 4;
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WN, wn = wave % WN;
 
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + LBN - 1) / LBN;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
   int wg = blockIdx.x;
   {
@@ -71,23 +139,23 @@ __global__ __launch_bounds__(L_THREADS) void scaled_mm_large_kernel(
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int tm = wg % tiles_m, tn = wg / tiles_m;
-  const int m0 = tm * BM, n0 = tn * LBN;
+  const int m0 = tm * BM, n0 = tn * BN;
 
-  // staging: in round r, wave w fills rows [64 r + 8 w, +8): lane -> (row = lane>>3, slot = lane&7)
+  // staging: in round r, wave w fills rows [RPR r + 8 w, +8): lane -> (row = lane>>3, slot = lane&7)
   // and loads logical chunk slot ^ f(row) so that the linear LDS image is the swizzled tile.
   // Sources are 32-bit offsets from the (uniform) operand base; the host checks they fit.
   const int srow = lane >> 3, sslot = lane & 7;
   uint32_t a_voff[A_ROUNDS], w_voff[W_ROUNDS];
 #pragma unroll
   for (int r = 0; r < A_ROUNDS; ++r) {
-    const int row = 64 * r + 8 * wave + srow;
+    const int row = RPR * r + 8 * wave + srow;
     int m = m0 + row;
     m = m < M ? m : M - 1;   // rows past M: any valid row (their outputs are never stored)
     a_voff[r] = (uint32_t)m * (uint32_t)lda + ((sslot ^ lswz(row)) << 4);
   }
 #pragma unroll
   for (int r = 0; r < W_ROUNDS; ++r) {
-    const int row = 64 * r + 8 * wave + srow;
+    const int row = RPR * r + 8 * wave + srow;
     int n = n0 + row;
     n = n < N ? n : N - 1;
     w_voff[r] = (uint32_t)n * (uint32_t)ldb + ((sslot ^ lswz(row)) << 4);
@@ -100,17 +168,17 @@ __global__ __launch_bounds__(L_THREADS) void scaled_mm_large_kernel(
     for (int r = 0; r < A_ROUNDS; ++r)
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(ag + a_voff[r]),
-          (__attribute__((address_space(3))) void*)(base + 64 * r * LBK), 16, 0, 0);
+          (__attribute__((address_space(3))) void*)(base + RPR * r * LBK), 16, 0, 0);
 #pragma unroll
     for (int r = 0; r < W_ROUNDS; ++r)
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(bg + w_voff[r]),
-          (__attribute__((address_space(3))) void*)(base + A_BYTES + 64 * r * LBK), 16, 0, 0);
+          (__attribute__((address_space(3))) void*)(base + A_BYTES + RPR * r * LBK), 16, 0, 0);
   };
 
-  f32x4 acc[4][MT];  // [nt][mt]
+  f32x4 acc[NT][MT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -121,105 +189,114 @@ __global__ __launch_bounds__(L_THREADS) void scaled_mm_large_kernel(
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int ch = ((2 * g4 + j) ^ lswz(c16)) << 4;
-    w_addr[j] = lds_base + A_BYTES + (wn * 64 + c16) * LBK + ch;
-    a_addr[j] = lds_base + (wm * (BM / 2) + c16) * LBK + ch;
+    w_addr[j] = lds_base + A_BYTES + (wn * (BN / WN) + c16) * LBK + ch;
+    a_addr[j] = lds_base + (wm * (BM / WM) + c16) * LBK + ch;
   }
-  constexpr int TOFF = 16 * LBK;
 
-  const int nk = K / LBK;
-  stage_load(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    // own DMA of this stage (issued one block ago) has landed; then everybody's has, and
-    // everybody is done reading the other stage
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // Ring of NST groups of KB blocks.  One wait + barrier per GROUP: groups g+1 .. g+NST-2 stay
+  // in flight while group g is consumed, and group g+NST-1 is issued into the buffers group
+  // g-1 just left.  (KB > 1 is for small tiles, where a barrier per block would leave the
+  // latency chain barrier -> ds_read -> MFMA exposed once per 2..4 MFMAs.)
+  const int ng = K / (LBK * KB);   // host guarantees K % (128 KB) == 0
+  auto group_load = [&](int buf, int g) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) stage_load(buf * KB + kb, (g * KB + kb) * LBK);
+  };
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < ng) group_load(s, s);
+  int cur = 0, nxt = NST - 1;   // buffer of group g / of group g + NST - 1
+  for (int g = 0; g < ng; ++g) {
+    // own DMA of group g has landed (in the steady state everything but the NST-2 younger
+    // groups; near the end fewer are in flight, so drain); then everybody's has, and
+    // everybody is done reading the buffer that is restaged next
+    if (g + NST - 1 <= ng) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * KB * LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) stage_load((kt + 1) & 1, (kt + 1) * LBK);
+    if (g + NST - 1 < ng) group_load(nxt, g + NST - 1);
 
-    const uint32_t so = (kt & 1) * STAGE;
+    const uint32_t so = cur * (KB * STAGE);
+    nxt = cur;
+    cur = cur + 1 == NST ? 0 : cur + 1;
     const uint32_t wa0 = w_addr[0] + so, wa1 = w_addr[1] + so;
     const uint32_t aa0 = a_addr[0] + so, aa1 = a_addr[1] + so;
-    i32x4 w0 = lds_read16<0 * TOFF>(wa0), w1 = lds_read16<0 * TOFF>(wa1);
-    i32x4 w2 = lds_read16<1 * TOFF>(wa0), w3 = lds_read16<1 * TOFF>(wa1);
-    i32x4 w4 = lds_read16<2 * TOFF>(wa0), w5 = lds_read16<2 * TOFF>(wa1);
-    i32x4 w6 = lds_read16<3 * TOFF>(wa0), w7 = lds_read16<3 * TOFF>(wa1);
-    i32x4 a0 = lds_read16<0>(aa0), a1 = lds_read16<0>(aa1);
-    i32x8 wf[4];
+
+    // Software pipeline over the KB * MT steps (kb, mt) of the group, fully unrolled: the
+    // fragments of step s+1 are requested before the MFMAs of step s, and every wait counts
+    // exactly the reads issued after the ones it needs.
+    i32x4 wl[2][NT], wh[2][NT];   // weight fragments of block kb in [kb & 1]
+    i32x4 al[2], ah[2];           // activation fragment of step s in [s & 1]
+    i32x8 wf[NT];
+    read_w<0, 0>(wa0, wa1, wl[0], wh[0]);
+    lds_read_frag<0, 0>(aa0, aa1, al[0], ah[0]);
+    static_for<KB * MT>([&](auto ic) {
+      constexpr int s = decltype(ic)::value;
+      constexpr int kb = s / MT, mt = s % MT;
+      constexpr int s1 = s + 1, kb1 = s1 / MT, mt1 = s1 % MT;
+      constexpr bool more = s1 < KB * MT;
+      constexpr bool next_w = more && mt1 == 0;
+      if constexpr (next_w) read_w<kb1 * STAGE, 0>(wa0, wa1, wl[kb1 & 1], wh[kb1 & 1]);
+      if constexpr (more) lds_read_frag<kb1 * STAGE, mt1>(aa0, aa1, al[s1 & 1], ah[s1 & 1]);
+      constexpr int later = (more ? 2 : 0) + (next_w ? 2 * NT : 0);
+      if constexpr (mt == 0) {
+        wait_frags<later>(wl[kb & 1], wh[kb & 1], al[s & 1], ah[s & 1]);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      i32x4 na0 = a0, na1 = a1;
-      if (mt + 1 < MT) {
-        // next A fragment: constant offsets need a compile-time mt -> unrolled switch
-        switch (mt + 1) {
-#define VA_CASE(T) case T: na0 = lds_read16<(T < MT ? T : 0) * TOFF>(aa0); \
-                           na1 = lds_read16<(T < MT ? T : 0) * TOFF>(aa1); break;
-          VA_CASE(1) VA_CASE(2) VA_CASE(3) VA_CASE(4) VA_CASE(5) VA_CASE(6) VA_CASE(7)
-#undef VA_CASE
-        }
-      }
-      if (mt == 0) {
-        if (MT > 1)
-          asm volatile("s_waitcnt lgkmcnt(2)"
-                       : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6),
-                         "+v"(w7), "+v"(a0), "+v"(a1));
-        else
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6),
-                         "+v"(w7), "+v"(a0), "+v"(a1));
-        wf[0] = cat8(w0, w1); wf[1] = cat8(w2, w3); wf[2] = cat8(w4, w5); wf[3] = cat8(w6, w7);
-      } else if (mt + 1 < MT) {
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0), "+v"(a1));
+        for (int nt = 0; nt < NT; ++nt) wf[nt] = cat8(wl[kb & 1][nt], wh[kb & 1][nt]);
       } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1));
+        wait_frag<later>(al[s & 1], ah[s & 1]);
       }
-      const i32x8 af = cat8(a0, a1);
+      const i32x8 af = cat8(al[s & 1], ah[s & 1]);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
         acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
             wf[nt], af, acc[nt][mt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-      a0 = na0; a1 = na1;
-    }
+    });
   }
 
   // ---- epilogue: lane holds C^T[n = 16 nt + 4 g4 + r][m = 16 mt + c16] ---------------
   // column scales / bias: loaded once, unconditionally, from clamped addresses
-  float sbv[4][4], biasv[4][4];
+  float sbv[NT][4], biasv[NT][4];
   const bool has_bias = bias != nullptr;
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * 64 + nt * 16 + 4 * g4 + r;
+      const int n = n0 + wn * (BN / WN) + nt * 16 + 4 * g4 + r;
       const int nn = n < N ? n : N - 1;
       sbv[nt][r] = b_scales[b_scale_numel == 1 ? 0 : nn];
       biasv[nt][r] = 0.f;
     }
   if (has_bias) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wn * 64 + nt * 16 + 4 * g4 + r;
+        const int n = n0 + wn * (BN / WN) + nt * 16 + 4 * g4 + r;
         biasv[nt][r] = to_f32(bias[n < N ? n : N - 1]);
       }
   }
   float sav[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int m = m0 + wm * (BM / 2) + mt * 16 + c16;
+    const int m = m0 + wm * (BM / WM) + mt * 16 + c16;
     sav[mt] = a_scales[a_scale_numel == 1 ? 0 : (m < M ? m : M - 1)];
   }
   if constexpr (VEC_STORE) {
-    // Coalesced store: the scaled tile goes through LDS (it overlays the staging buffers)
-    // as [BM rows][512 B], 16-byte chunks XOR-swizzled by (row & 7); then every store
-    // instruction writes two full 512-byte rows.  Direct stores from the MFMA layout write
-    // 32-byte pieces of 16 different rows per instruction and cost 25 us on a 32 MB output.
+    // tile through LDS as [BM rows][BN * 2 B], 16-byte chunks XOR-swizzled by the row;
+    // then each store instruction writes 512 / BN whole rows
     static_assert(sizeof(out_t) == 2, "");
+    constexpr int ROWB = BN * 2;                 // bytes per tile row
+    constexpr int CPR = BN / 8;                  // 16-byte chunks per row
+    constexpr int SWZ = (CPR < 8 ? CPR : 8) - 1; // chunk ^= row & SWZ stays inside the row
+    constexpr int RPI = 64 / CPR;                // rows per store instruction
+    static_assert(BM % (RPI * NW) == 0, "");
+    static_assert(BM * ROWB <= NST * KB * STAGE, "");
     __syncthreads();   // every wave is past its last fragment read
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int row = wm * (BM / 2) + mt * 16 + c16;
+      const int row = wm * (BM / WM) + mt * 16 + c16;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < NT; ++nt) {
         struct alignas(8) V4 { out_t e[4]; } pk;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -229,29 +306,29 @@ __global__ __launch_bounds__(L_THREADS) void scaled_mm_large_kernel(
           if (has_bias) o = from_f32<out_t>(to_f32(o) + biasv[nt][r]);
           pk.e[r] = o;
         }
-        const int c8 = wn * 16 + nt * 4 + g4;   // 8-byte chunk within the row
-        *reinterpret_cast<V4*>(lds + row * 512 + ((c8 ^ (2 * (row & 7))) << 3)) = pk;
+        const int c8 = wn * (BN / WN / 4) + nt * 4 + g4;   // 8-byte chunk within the row
+        *reinterpret_cast<V4*>(lds + row * ROWB + ((c8 ^ (2 * (row & SWZ))) << 3)) = pk;
       }
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < BM / 16; ++i) {
-      const int row = 2 * (wave * (BM / 16) + i) + (lane >> 5);
-      const int c16b = lane & 31;               // 16-byte chunk = 8 outputs
-      const uint4 v = *reinterpret_cast<const uint4*>(lds + row * 512 + ((c16b ^ (row & 7)) << 4));
-      const int m = m0 + row, n = n0 + 8 * c16b;
+    for (int i = 0; i < BM / (RPI * NW); ++i) {
+      const int row = RPI * (wave * (BM / (RPI * NW)) + i) + lane / CPR;
+      const int ch = lane % CPR;                 // 16-byte chunk = 8 outputs
+      const uint4 v = *reinterpret_cast<const uint4*>(lds + row * ROWB + ((ch ^ (row & SWZ)) << 4));
+      const int m = m0 + row, n = n0 + 8 * ch;
       if (m < M && n < N) *reinterpret_cast<uint4*>(out + (int64_t)m * ldc + n) = v;
     }
     return;
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int m = m0 + wm * (BM / 2) + mt * 16 + c16;
+    const int m = m0 + wm * (BM / WM) + mt * 16 + c16;
     if (m >= M) continue;
     const float sa = sav[mt];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = n0 + wn * 64 + nt * 16 + 4 * g4;
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wn * (BN / WN) + nt * 16 + 4 * g4;
       if (n >= N) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -266,41 +343,61 @@ __global__ __launch_bounds__(L_THREADS) void scaled_mm_large_kernel(
   }
 }
 
-template <typename out_t, int BM>
-static void launch_large_t(void* out, const void* a, const void* b, const float* a_scales,
-                           const float* b_scales, const void* bias, int M, int N, int K,
-                           int64_t lda, int64_t ldb, int64_t ldc, int asn, int bsn, bool vec,
-                           hipStream_t st) {
-  const int tiles = ((M + BM - 1) / BM) * ((N + LBN - 1) / LBN);
-  if (vec)
-    hipLaunchKernelGGL((scaled_mm_large_kernel<out_t, BM, true>), dim3(tiles), dim3(L_THREADS), 0,
-                       st, (out_t*)out, (const uint8_t*)a, (const uint8_t*)b, a_scales, b_scales,
-                       (const out_t*)bias, M, N, K, lda, ldb, ldc, asn, bsn);
+struct GldsArgs {
+  void* out; const void* a; const void* b; const float* a_scales; const float* b_scales;
+  const void* bias; int M, N, K; int64_t lda, ldb, ldc; int asn, bsn; bool vec; hipStream_t st;
+};
+
+template <typename out_t, int BM, int BN, int WM, int WN, int NST, int KB>
+static void launch_glds_t(const GldsArgs& g) {
+  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  if (g.vec)
+    hipLaunchKernelGGL((scaled_mm_glds_kernel<out_t, BM, BN, WM, WN, NST, KB, true>), dim3(tiles),
+                       dim3(64 * WM * WN), 0, g.st, (out_t*)g.out, (const uint8_t*)g.a,
+                       (const uint8_t*)g.b, g.a_scales, g.b_scales, (const out_t*)g.bias, g.M, g.N,
+                       g.K, g.lda, g.ldb, g.ldc, g.asn, g.bsn);
   else
-    hipLaunchKernelGGL((scaled_mm_large_kernel<out_t, BM, false>), dim3(tiles), dim3(L_THREADS), 0,
-                       st, (out_t*)out, (const uint8_t*)a, (const uint8_t*)b, a_scales, b_scales,
-                       (const out_t*)bias, M, N, K, lda, ldb, ldc, asn, bsn);
+    hipLaunchKernelGGL((scaled_mm_glds_kernel<out_t, BM, BN, WM, WN, NST, KB, false>), dim3(tiles),
+                       dim3(64 * WM * WN), 0, g.st, (out_t*)g.out, (const uint8_t*)g.a,
+                       (const uint8_t*)g.b, g.a_scales, g.b_scales, (const out_t*)g.bias, g.M, g.N,
+                       g.K, g.lda, g.ldb, g.ldc, g.asn, g.bsn);
 }
 
-// The kernel addresses its operands with 32-bit byte offsets.
+template <typename out_t>
+static void launch_glds_shape(int shape, const GldsArgs& g) {
+  switch (shape) {
+    case 2: launch_glds_t<out_t, 256, 256, 2, 4, 2, 1>(g); break;
+    case 3: launch_glds_t<out_t, 128, 128, 2, 4, 2, 1>(g); break;
+    case 4: launch_glds_t<out_t, 128, 128, 2, 4, 2, 2>(g); break;
+    case 5: launch_glds_t<out_t, 128, 64, 4, 2, 3, 1>(g); break;
+    case 6: launch_glds_t<out_t, 128, 64, 4, 2, 3, 2>(g); break;
+    case 7: launch_glds_t<out_t, 64, 64, 2, 2, 4, 1>(g); break;
+    case 8: launch_glds_t<out_t, 64, 64, 2, 2, 2, 4>(g); break;
+    case 9: launch_glds_t<out_t, 64, 32, 2, 2, 4, 1>(g); break;
+    default: launch_glds_t<out_t, 64, 32, 2, 2, 3, 4>(g); break;   // 10
+  }
+}
+
+// The kernels address their operands with 32-bit byte offsets.
 bool scaled_mm_large_fits(int M, int N, int K, int64_t lda, int64_t ldb) {
   const int64_t lim = (int64_t)1 << 32;
   return (int64_t)M * lda + K < lim && (int64_t)N * ldb + K < lim;
 }
 
-// bm = 256 or 128; caller guarantees K % 128 == 0, 16-byte aligned operands and
-// scaled_mm_large_fits().
-void launch_scaled_mm_large(int bm, void* out, const void* a, const void* b,
+// Caller guarantees K % 128 == 0, 16-byte aligned operands and scaled_mm_large_fits();
+// vec = 16-byte aligned output rows (ldc % 8 == 0, N % 8 == 0, out 16-byte aligned).
+void launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
                             const float* a_scales, const float* b_scales, const void* bias, int M,
                             int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int asn, int bsn,
                             int out_dtype, bool vec, hipStream_t st) {
-  if (out_dtype == VLLM_AMD_BF16) {
-    if (bm == 256) launch_large_t<bf16_t, 256>(out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc, asn, bsn, vec, st);
-    else launch_large_t<bf16_t, 128>(out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc, asn, bsn, vec, st);
-  } else {
-    if (bm == 256) launch_large_t<f16_t, 256>(out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc, asn, bsn, vec, st);
-    else launch_large_t<f16_t, 128>(out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc, asn, bsn, vec, st);
-  }
+  // shape = a GldsTile::id of the table in scaled_mm.hip.  Shapes that consume KB blocks per
+  // barrier need K % (128 KB) == 0; otherwise the same tile with KB = 1.
+  static const int kb_of[11] = {1, 1, 1, 1, 2, 1, 2, 1, 4, 1, 4};
+  if (shape < 2 || shape > 10) shape = 3;
+  if (K % (LBK * kb_of[shape]) != 0) shape -= 1;
+  const GldsArgs g{out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc, asn, bsn, vec, st};
+  if (out_dtype == VLLM_AMD_BF16) launch_glds_shape<bf16_t>(shape, g);
+  else launch_glds_shape<f16_t>(shape, g);
 }
 
 }  // namespace va
