@@ -200,6 +200,65 @@ int vllm_amd_wvSplitKQ(const void* in_a, const void* in_b, void* out_c,
                        void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Neighbours of the path: the ops that produce the GEMM's fp8   */
+/* activations and the cache write's slot mapping.                              */
+/* ------------------------------------------------------------------------- */
+
+/* Replaces torch.ops._C.rms_norm_static_fp8_quant
+ * (csrc/layernorm_quant_kernels.cu:25-58, 172-198; schema torch_bindings.cpp:190-195;
+ * wrapper vllm/_custom_ops.py:283-286).
+ * out[t, i] = fp8(clamp(scalar_t(x * rsqrt(mean(x^2) + eps)) * weight[i] * (1 / *scale))).
+ * input rows are input_stride elements apart; out is contiguous [num_tokens, hidden]. */
+int vllm_amd_rms_norm_static_fp8_quant(void* out, const void* input,
+                                       const void* weight, const float* scale,
+                                       float epsilon, int64_t num_tokens,
+                                       int hidden_size, int64_t input_stride,
+                                       int dtype, void* stream);
+
+/* Replaces torch.ops._C.fused_add_rms_norm_static_fp8_quant
+ * (csrc/layernorm_quant_kernels.cu:64-168, 214-253; wrapper _custom_ops.py:289-293).
+ * residual <- scalar_t(input + residual) (in place, contiguous), then as above on it. */
+int vllm_amd_fused_add_rms_norm_static_fp8_quant(void* out, const void* input,
+                                                 void* residual, const void* weight,
+                                                 const float* scale, float epsilon,
+                                                 int64_t num_tokens, int hidden_size,
+                                                 int64_t input_stride, int dtype,
+                                                 void* stream);
+
+/* Replaces torch.ops._C.rms_norm_dynamic_per_token_quant for fp8 output
+ * (csrc/quantization/fused_kernels/fused_layernorm_dynamic_per_token_quant.cu:11-155,
+ * layernorm_utils.cuh:20-119; wrapper _custom_ops.py:368-384).  scale_ub and residual
+ * may be NULL; scales is float[num_tokens] (out); residual is updated in place with
+ * scalar_t(input + residual).  int8 output is outside this path (VLLM_AMD_EUNSUPPORTED
+ * is raised by the Python layer). */
+int vllm_amd_rms_norm_dynamic_per_token_quant(void* out, const void* input,
+                                              const void* weight, float* scales,
+                                              float epsilon, const float* scale_ub,
+                                              void* residual, int64_t num_tokens,
+                                              int hidden_size, int dtype, void* stream);
+
+/* Replaces torch.ops._C.silu_and_mul_quant (csrc/quantization/activation_kernels.cu:14-121).
+ * input [num_tokens, 2 d] (f16 / bf16): out[t, i] = fp8(clamp(T(silu(x)) * y * (1 / *scale))). */
+int vllm_amd_silu_and_mul_quant(void* out, const void* input, const float* scale,
+                                int64_t num_tokens, int d, int dtype, void* stream);
+
+/* Device-side BlockTable.compute_slot_mapping (vllm/v1/worker/block_table.py:84-99):
+ * slot_mapping[i] = block_table[req_indices[i], positions[i] / block_size] * block_size
+ *                   + positions[i] % block_size.  The reference computes this with numpy
+ * on the host and copies it to the GPU every step (commit_slot_mapping, :105-107). */
+int vllm_amd_compute_slot_mapping(int64_t* slot_mapping, const int32_t* block_table,
+                                  const int32_t* req_indices, const int64_t* positions,
+                                  int64_t num_tokens, int max_num_blocks_per_req,
+                                  int block_size, void* stream);
+
+/* Replaces torch.ops._C_cache_ops.swap_blocks (csrc/cache_kernels.cu:25-67):
+ * block_mapping_host is a HOST array of num_pairs (src, dst) int64 pairs; src / dst may
+ * each be device or host memory (block_bytes per block number). */
+int vllm_amd_swap_blocks(const void* src, void* dst, int64_t block_bytes,
+                         const int64_t* block_mapping_host, int64_t num_pairs,
+                         void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Tuning knobs (no counterpart in the reference): used by tools/ and bench   */
 /* scripts to A/B kernel variants inside one process.                          */
 /*   "pa_variant": bit 0 = non-temporal K/V loads, bit 1 = two steps of K/V    */

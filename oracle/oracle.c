@@ -683,3 +683,117 @@ void oracle_paged_attention_f64(
       free(lg);
     }
 }
+
+/* ------------------------------------------------------------------ */
+/* fused neighbours of the GEMM                       */
+/* ------------------------------------------------------------------ */
+/* 1/rms as the kernels compute it: rsqrtf(ss / hidden + eps); the sum of squares
+ * is taken in double here (the reference's order is a 1024-thread tree in fp32:
+ * layernorm_utils.cuh:26-47), so results agree to fp32 rounding only. */
+static inline float inv_rms(double ss, int hidden, float eps) {
+  return 1.0f / sqrtf((float)ss / (float)hidden + eps);
+}
+/* scalar_t(x * rms) * weight, product rounded in scalar_t
+ * (layernorm_utils.cuh:114, layernorm_quant_kernels.cu:54) */
+static inline float norm_elem(float x, float rms, float w, int dt) {
+  return round_to(round_to(x * rms, dt) * w, dt);
+}
+
+/* csrc/layernorm_quant_kernels.cu:25-58 */
+void oracle_rms_norm_static_fp8_quant(uint8_t* out, const void* in, int64_t in_stride,
+                                      const void* weight, float scale, float eps,
+                                      int64_t num_tokens, int hidden, int dt) {
+  const float inv = 1.0f / scale;
+  for (int64_t t = 0; t < num_tokens; ++t) {
+    double ss = 0;
+    for (int i = 0; i < hidden; ++i) {
+      float x = load_as_f32(in, t * in_stride + i, dt);
+      ss += (double)x * x;
+    }
+    const float r = inv_rms(ss, hidden, eps);
+    for (int i = 0; i < hidden; ++i) {
+      float x = load_as_f32(in, t * in_stride + i, dt);
+      out[t * hidden + i] = quant_conv(norm_elem(x, r, load_as_f32(weight, i, dt), dt), inv, 1);
+    }
+  }
+}
+
+/* csrc/layernorm_quant_kernels.cu:64-168: z = input + residual rounded to scalar_t
+ * (written back to residual), variance over z, then as above. */
+void oracle_fused_add_rms_norm_static_fp8_quant(uint8_t* out, const void* in,
+                                                int64_t in_stride, void* residual,
+                                                const void* weight, float scale, float eps,
+                                                int64_t num_tokens, int hidden, int dt) {
+  const float inv = 1.0f / scale;
+  for (int64_t t = 0; t < num_tokens; ++t) {
+    double ss = 0;
+    for (int i = 0; i < hidden; ++i) {
+      float z = round_to(load_as_f32(in, t * in_stride + i, dt) +
+                         load_as_f32(residual, t * hidden + i, dt), dt);
+      store_from_f32(residual, t * hidden + i, dt, z);
+      ss += (double)z * z;
+    }
+    const float r = inv_rms(ss, hidden, eps);
+    for (int i = 0; i < hidden; ++i) {
+      float z = load_as_f32(residual, t * hidden + i, dt);
+      out[t * hidden + i] = quant_conv(norm_elem(z, r, load_as_f32(weight, i, dt), dt), inv, 1);
+    }
+  }
+}
+
+/* csrc/quantization/fused_kernels/fused_layernorm_dynamic_per_token_quant.cu:11-85 with
+ * layernorm_utils.cuh:20-119: x = float(in) (+ float(residual), NOT rounded; residual is
+ * overwritten with scalar_t(x)); token scale = max(min(absmax, ub) / 448, 1/(448*512));
+ * fp8 output divides by the scale ("do not invert", :38-41). */
+void oracle_rms_norm_dynamic_per_token_quant(uint8_t* out, const void* in, const void* weight,
+                                             float* scales, float eps, const float* scale_ub,
+                                             void* residual, int64_t num_tokens, int hidden,
+                                             int dt) {
+  const float min_scale = 1.0f / (FP8_MAX * 512.0f);
+  float* xs = (float*)malloc(sizeof(float) * (size_t)(hidden > 0 ? hidden : 1));
+  for (int64_t t = 0; t < num_tokens; ++t) {
+    double ss = 0;
+    for (int i = 0; i < hidden; ++i) {
+      float x = load_as_f32(in, t * hidden + i, dt);
+      if (residual) x += load_as_f32(residual, t * hidden + i, dt);
+      xs[i] = x;
+      ss += (double)x * x;
+    }
+    const float r = inv_rms(ss, hidden, eps);
+    float amax = 0.f;
+    for (int i = 0; i < hidden; ++i)
+      amax = fmaxf(amax, fabsf(norm_elem(xs[i], r, load_as_f32(weight, i, dt), dt)));
+    float s = scale_ub ? fminf(amax, *scale_ub) : amax;
+    s = fmaxf(s / FP8_MAX, min_scale);
+    scales[t] = s;
+    for (int i = 0; i < hidden; ++i) {
+      if (residual) store_from_f32(residual, t * hidden + i, dt, xs[i]);
+      out[t * hidden + i] = quant_conv(norm_elem(xs[i], r, load_as_f32(weight, i, dt), dt), s, 0);
+    }
+  }
+  free(xs);
+}
+
+/* csrc/quantization/activation_kernels.cu:14-89: out = fp8(T(silu(x)) * y in T, times 1/scale);
+ * input [..., 2, d] (x then y), f16 / bf16 only (:117-118). */
+void oracle_silu_and_mul_quant(uint8_t* out, const void* in, float scale, int64_t num_tokens,
+                               int d, int dt) {
+  const float inv = 1.0f / scale;
+  for (int64_t t = 0; t < num_tokens; ++t)
+    for (int i = 0; i < d; ++i) {
+      float x = load_as_f32(in, t * 2 * d + i, dt);
+      float y = load_as_f32(in, t * 2 * d + d + i, dt);
+      float a = round_to(x / (1.0f + expf(-x)), dt);
+      out[t * d + i] = quant_conv(round_to(a * y, dt), inv, 1);
+    }
+}
+
+/* vllm/v1/worker/block_table.py:84-99 */
+void oracle_compute_slot_mapping(int64_t* slot_mapping, const int32_t* block_table,
+                                 const int32_t* req_indices, const int64_t* positions,
+                                 int64_t num_tokens, int max_blocks_per_req, int block_size) {
+  for (int64_t i = 0; i < num_tokens; ++i) {
+    int64_t bi = (int64_t)req_indices[i] * max_blocks_per_req + positions[i] / block_size;
+    slot_mapping[i] = (int64_t)block_table[bi] * block_size + positions[i] % block_size;
+  }
+}

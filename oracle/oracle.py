@@ -249,3 +249,65 @@ def paged_attention_f64(query, key_cache, value_cache, num_kv_heads, scale,
                         kv_cache_dtype, k_scale, v_scale)
     lib().oracle_paged_attention_f64(_p(out), *args)
     return out
+
+
+# ---- neighbours of the path ---------------------------------------------
+# vllm/_custom_ops.py:283-286 (torch.ops._C.rms_norm_static_fp8_quant)
+def rms_norm_static_fp8_quant(input, weight, scale: float, epsilon: float) -> torch.Tensor:
+    hidden = input.shape[-1]
+    nt = input.numel() // hidden
+    out = torch.empty(input.shape, dtype=torch.uint8)
+    stride = input.stride(-2) if input.dim() >= 2 else hidden
+    lib().oracle_rms_norm_static_fp8_quant(_p(out), _p(input), _i64(stride), _p(weight),
+                                           _f(scale), _f(epsilon), _i64(nt), hidden,
+                                           DT[input.dtype])
+    return out
+
+
+# vllm/_custom_ops.py:289-293; residual is updated in place
+def fused_add_rms_norm_static_fp8_quant(input, residual, weight, scale: float,
+                                        epsilon: float) -> torch.Tensor:
+    hidden = input.shape[-1]
+    nt = input.numel() // hidden
+    assert residual.is_contiguous()
+    out = torch.empty(input.shape, dtype=torch.uint8)
+    stride = input.stride(-2) if input.dim() >= 2 else hidden
+    lib().oracle_fused_add_rms_norm_static_fp8_quant(
+        _p(out), _p(input), _i64(stride), _p(residual), _p(weight), _f(scale), _f(epsilon),
+        _i64(nt), hidden, DT[input.dtype])
+    return out
+
+
+# vllm/_custom_ops.py:368-384 (fp8 output); residual is updated in place
+def rms_norm_dynamic_per_token_quant(input, weight, epsilon: float, scale_ub=None,
+                                     residual=None):
+    assert input.is_contiguous()
+    hidden = input.shape[-1]
+    nt = input.numel() // hidden
+    out = torch.empty(input.shape, dtype=torch.uint8)
+    scales = torch.empty((nt, 1), dtype=torch.float32)
+    ub = None if scale_ub is None else scale_ub.float().reshape(1).contiguous()
+    lib().oracle_rms_norm_dynamic_per_token_quant(
+        _p(out), _p(input), _p(weight), _p(scales), _f(epsilon), _p(ub), _p(residual), _i64(nt),
+        hidden, DT[input.dtype])
+    return out, scales
+
+
+# torch.ops._C.silu_and_mul_quant (csrc/quantization/activation_kernels.cu:112-121)
+def silu_and_mul_quant(input, scale: float) -> torch.Tensor:
+    assert input.is_contiguous()
+    d = input.shape[-1] // 2
+    nt = input.numel() // input.shape[-1]
+    out = torch.empty(input.shape[:-1] + (d,), dtype=torch.uint8)
+    lib().oracle_silu_and_mul_quant(_p(out), _p(input), _f(scale), _i64(nt), d, DT[input.dtype])
+    return out
+
+
+# vllm/v1/worker/block_table.py:84-99
+def compute_slot_mapping(block_table, req_indices, positions, block_size: int) -> torch.Tensor:
+    n = req_indices.shape[0]
+    out = torch.empty(n, dtype=torch.int64)
+    lib().oracle_compute_slot_mapping(_p(out), _p(block_table.contiguous()),
+                                      _p(req_indices.contiguous()), _p(positions.contiguous()),
+                                      _i64(n), block_table.shape[1], block_size)
+    return out

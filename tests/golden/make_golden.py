@@ -13,6 +13,12 @@ Sources of the expected outputs
                     ref_dynamic_per_tensor_fp8_quant) using torch.float8_e4m3fn casts
   scaled_mm_*.pt    torch CPU restatement of baseline_scaled_mm (tests/kernels/utils.py:1212-1251)
   fp8_codec.pt      all 256 e4m3fn codes decoded by torch + an encode sweep by torch casts
+  fused_quant_*.pt  torch CPU restatement of the "native" side of the reference's tests:
+                    RMSNorm.forward_native (vllm/model_executor/layers/layernorm.py) followed by
+                    ops.scaled_fp8_quant (tests/kernels/core/test_fused_quant_layernorm.py:40-74),
+                    SiluAndMul.forward_native + static quant
+                    (tests/kernels/test_fused_quant_activation.py:21-25)
+  slot_mapping.pt   numpy arithmetic of BlockTable.compute_slot_mapping (block_table.py:92-99)
 The fixtures are DATA only; nothing of the reference's source text is stored.
 """
 import os
@@ -128,5 +134,82 @@ def fp8_codec():
     save("fp8_codec.pt", dict(dec=dec, x=x, enc=enc))
 
 
+def _rms_native(x, weight, eps, residual=None):
+    """RMSNorm.forward_native: fp32 maths, one rounding to the input dtype before the weight."""
+    dt = x.dtype
+    xf = x.float()
+    new_res = None
+    if residual is not None:
+        xf = xf + residual.float()
+        new_res = xf.to(dt)
+    var = xf.pow(2).mean(dim=-1, keepdim=True)
+    y = (xf * torch.rsqrt(var + eps)).to(dt) * weight
+    return y, new_res
+
+
+def _q_static(y, scale):
+    # static_scaled_fp8_quant (common.cu:21-25): the reciprocal is taken in fp32
+    inv = 1.0 / torch.tensor(scale, dtype=torch.float32)
+    return (y.float() * inv).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def fused_quant():
+    g = torch.Generator().manual_seed(21)
+    min_scale = 1.0 / (FP8_MAX * 512.0)
+    eps = 1e-6
+    for dtype, tag in ((torch.bfloat16, "bf16"), (torch.float16, "fp16"), (torch.float32, "fp32")):
+        T, H = 7, 1032
+        x = (torch.randn((T, H), generator=g) * 0.7).to(dtype)
+        res = (torch.randn((T, H), generator=g) * 0.7).to(dtype)
+        w = (1.0 + 0.1 * torch.randn(H, generator=g)).to(dtype)
+        scale = 0.02
+        out = dict(x=x, res=res, w=w, scale=torch.tensor(scale), eps=torch.tensor(eps))
+        y, _ = _rms_native(x, w, eps)
+        out["static_q"] = _q_static(y, scale)
+        # fused add (static): the reference kernel rounds input + residual to the dtype first
+        z = (x.float() + res.float()).to(dtype)
+        y, _ = _rms_native(z, w, eps)
+        out["add_static_q"], out["add_static_res"] = _q_static(y, scale), z
+        for name, r in (("dyn", None), ("dynres", res)):
+            y, new_res = _rms_native(x, w, eps, r)
+            yf = y.float()
+            amax = yf.abs().amax(dim=-1, keepdim=True)
+            ub = torch.tensor([amax.mean().item()])
+            out["ub"] = ub
+            for ubname, am in (("", amax), ("_ub", amax.clamp(max=ub))):
+                sc = (am / FP8_MAX).clamp(min=min_scale)
+                out[f"{name}{ubname}_q"] = (yf / sc).clamp(-FP8_MAX, FP8_MAX).to(
+                    torch.float8_e4m3fn).view(torch.uint8)
+                out[f"{name}{ubname}_s"] = sc
+            if new_res is not None:
+                out["dynres_res"] = new_res
+        if dtype != torch.float32:
+            xs = (torch.randn((T, 2 * 520), generator=g) * 2).to(dtype)
+            d = 520
+            act = torch.nn.functional.silu(xs[:, :d]) * xs[:, d:]
+            out["silu_x"] = xs
+            out["silu_q"] = _q_static(act, 0.03)
+            out["silu_scale"] = torch.tensor(0.03)
+        save(f"fused_quant_{tag}.pt", out)
+
+
+def slot_mapping():
+    import numpy as np
+    rng = np.random.default_rng(3)
+    R, MB, BS = 6, 40, 16
+    bt = rng.permutation(R * MB).astype(np.int32).reshape(R, MB)
+    req = rng.integers(0, R, size=300).astype(np.int32)
+    pos = rng.integers(0, MB * BS, size=300).astype(np.int64)
+    idx = req * MB + pos // BS
+    slots = bt.flatten()[idx].astype(np.int64) * BS + pos % BS
+    save("slot_mapping.pt", dict(bt=torch.from_numpy(bt), req=torch.from_numpy(req),
+                                 pos=torch.from_numpy(pos), slots=torch.from_numpy(slots),
+                                 block_size=torch.tensor(BS)))
+
+
 if __name__ == "__main__":
-    attention(); cache(); fp8_quant(); scaled_mm(); fp8_codec()
+    if len(sys.argv) > 1:
+        for name in sys.argv[1:]:
+            globals()[name]()
+    else:
+        attention(); cache(); fp8_quant(); scaled_mm(); fp8_codec(); fused_quant(); slot_mapping()

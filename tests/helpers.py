@@ -59,3 +59,14 @@ def make_attn_case(num_seqs, num_heads, num_kv_heads, head_size, block_size, dty
 
 def to_dev(t, dev="cuda"):
     return None if t is None else t.to(dev)
+
+
+def codes_close(a, b, max_frac):
+    """fp8 codes equal except for a small fraction that may sit one code apart (a value
+    within fp32 rounding of a tie: the variance is summed in a different order)."""
+    a, b = a.view(torch.uint8).flatten().int(), b.view(torch.uint8).flatten().int()
+    diff = a != b
+    # neighbouring codes of the same sign differ by 1; +-0 by 0x80
+    adj = ((a - b).abs() == 1) | ((a & 0x7f) + (b & 0x7f) <= 1)
+    assert bool((diff & ~adj).sum() == 0), "codes differ by more than one step"
+    assert diff.float().mean().item() <= max_frac, f"{int(diff.sum())} of {diff.numel()} codes differ"

@@ -20,7 +20,7 @@ def declared_symbols():
 def test_library_exports_every_declared_symbol():
     from vllm_amd import _lib
     syms = declared_symbols()
-    assert len(syms) >= 15
+    assert len(syms) >= 21
     for s in syms:
         assert hasattr(_lib.lib, s), f"{s} declared in include/vllm_amd.h but not exported"
     # and the ctypes signatures cover every entry point that takes arguments
@@ -49,6 +49,11 @@ SCHEMAS = {
     "_C_cache_ops::reshape_and_cache": "(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, Tensor slot_mapping, str kv_cache_dtype, Tensor k_scale, Tensor v_scale) -> ()",
     "_C_cache_ops::convert_fp8": "(Tensor! dst_cache, Tensor src_cache, float scale, str kv_cache_dtype) -> ()",
     "_rocm_C::wvSplitKQ": "(Tensor in_a, Tensor in_b, Tensor! out_c, Tensor scale_a, Tensor scale_b, int CuCount) -> ()",
+    # csrc/torch_bindings.cpp:117-120, 188-211
+    "_C::silu_and_mul_quant": "(Tensor! result, Tensor input, Tensor scale) -> ()",
+    "_C::rms_norm_static_fp8_quant": "(Tensor! result, Tensor input, Tensor weight, Tensor scale, float epsilon) -> ()",
+    "_C::fused_add_rms_norm_static_fp8_quant": "(Tensor! result, Tensor input, Tensor! residual, Tensor weight, Tensor scale, float epsilon) -> ()",
+    "_C::rms_norm_dynamic_per_token_quant": "(Tensor! result, Tensor input, Tensor weight, Tensor! scale, float epsilon, Tensor? scale_ub, Tensor!? residual) -> ()",
 }
 
 

@@ -206,3 +206,30 @@ def wvSplitKQ(a: torch.Tensor, b: torch.Tensor, out_dtype: torch.dtype, scale_a:
     out = torch.empty((b.shape[0], a.shape[0]), dtype=out_dtype, device=b.device)
     torch.ops._rocm_C.wvSplitKQ(a, b, out, scale_a, scale_b, cu_count)
     return out
+
+
+# ---- fused neighbours of the GEMM (vllm/_custom_ops.py:283-293, 368-384) -----------------
+def scaled_rms_norm(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor,
+                    scale: torch.Tensor, epsilon: float) -> None:
+    torch.ops._C.rms_norm_static_fp8_quant(out, input, weight, scale, epsilon)
+
+
+def scaled_fused_add_rms_norm(out: torch.Tensor, input: torch.Tensor, residual: torch.Tensor,
+                              weight: torch.Tensor, scale: torch.Tensor, epsilon: float) -> None:
+    torch.ops._C.fused_add_rms_norm_static_fp8_quant(out, input, residual, weight, scale, epsilon)
+
+
+def rms_norm_dynamic_per_token_quant(
+        input: torch.Tensor, weight: torch.Tensor, epsilon: float, quant_dtype: torch.dtype,
+        scale_ub: Optional[torch.Tensor] = None,
+        residual: Optional[torch.Tensor] = None) -> tuple[torch.Tensor, torch.Tensor]:
+    output = torch.empty_like(input, dtype=quant_dtype)
+    scales = torch.empty((input.numel() // input.shape[-1], 1), device=input.device,
+                         dtype=torch.float32)
+    torch.ops._C.rms_norm_dynamic_per_token_quant(output, input, weight, scales, epsilon,
+                                                  scale_ub, residual)
+    return output, scales
+
+
+def silu_and_mul_quant(out: torch.Tensor, input: torch.Tensor, scale: torch.Tensor) -> None:
+    torch.ops._C.silu_and_mul_quant(out, input, scale)

@@ -41,6 +41,14 @@ SIGNATURES = {
     "vllm_amd_scaled_mm": [
         _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _vp],
     "vllm_amd_wvSplitKQ": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "vllm_amd_rms_norm_static_fp8_quant": [_vp, _vp, _vp, _vp, _f, _i64, _i, _i64, _i, _vp],
+    "vllm_amd_fused_add_rms_norm_static_fp8_quant": [
+        _vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _i64, _i, _vp],
+    "vllm_amd_rms_norm_dynamic_per_token_quant": [
+        _vp, _vp, _vp, _vp, _f, _vp, _vp, _i64, _i, _i, _vp],
+    "vllm_amd_silu_and_mul_quant": [_vp, _vp, _vp, _i64, _i, _i, _vp],
+    "vllm_amd_compute_slot_mapping": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "vllm_amd_swap_blocks": [_vp, _vp, _i64, _vp, _i64, _vp],
     "vllm_amd_set_tuning": [C.c_char_p, _i],
 }
 

@@ -196,16 +196,110 @@ def copy_blocks(key_caches, value_caches, block_mapping) -> None:
 
 
 def swap_blocks(src, dst, block_mapping) -> None:
-    # csrc/cache_kernels.cu:25-67: per-pair async copies on the current stream;
-    # block_mapping must live on the CPU.
+    # csrc/cache_kernels.cu:25-67: per-pair async copies on the current stream of the
+    # device side; block_mapping must live on the CPU.
     if block_mapping.device.type != "cpu":
         raise RuntimeError("block_mapping must be on CPU")
     if src.is_cuda and dst.is_cuda and src.device != dst.device:
         raise RuntimeError("src and dst must be on the same GPU")
     if not (src.is_cuda or dst.is_cuda):
         raise RuntimeError("Invalid device combination")
-    for s, d in block_mapping.tolist():
-        dst[d].copy_(src[s], non_blocking=True)
+    bm = block_mapping.to(torch.int64).contiguous()
+    gpu = src if src.is_cuda else dst
+    block_bytes = src.element_size() * src.stride(0)
+    with _dev(gpu):
+        check(lib.vllm_amd_swap_blocks(_ptr(src), _ptr(dst), block_bytes, _ptr(bm), bm.shape[0],
+                                       _stream(gpu)))
+
+
+# ---- neighbours of the path --------------------------------------------
+def _fp8_out(result) -> None:
+    if result.dtype not in _FP8_DTYPES:
+        raise RuntimeError(f"Unsupported fp8 type: {result.dtype}")
+    if not result.is_contiguous():
+        raise RuntimeError("out.is_contiguous()")
+
+
+def rms_norm_static_fp8_quant(result, input, weight, scale, epsilon) -> None:
+    # csrc/layernorm_quant_kernels.cu:172-198
+    _cuda(result, input, weight, scale)
+    _fp8_out(result)
+    hidden = input.shape[-1]
+    nt = input.numel() // hidden if hidden else 0
+    stride = input.stride(-2) if input.dim() >= 2 else hidden
+    with _dev(input):
+        check(lib.vllm_amd_rms_norm_static_fp8_quant(
+            _ptr(result), _ptr(input), _ptr(weight), _ptr(scale), float(epsilon), nt, hidden,
+            stride, _dt(input), _stream(input)))
+
+
+def fused_add_rms_norm_static_fp8_quant(result, input, residual, weight, scale, epsilon) -> None:
+    # csrc/layernorm_quant_kernels.cu:214-253
+    _cuda(result, input, residual, weight, scale)
+    _fp8_out(result)
+    if not residual.is_contiguous():
+        raise RuntimeError("residual.is_contiguous()")
+    hidden = input.shape[-1]
+    nt = input.numel() // hidden if hidden else 0
+    stride = input.stride(-2) if input.dim() >= 2 else hidden
+    with _dev(input):
+        check(lib.vllm_amd_fused_add_rms_norm_static_fp8_quant(
+            _ptr(result), _ptr(input), _ptr(residual), _ptr(weight), _ptr(scale), float(epsilon),
+            nt, hidden, stride, _dt(input), _stream(input)))
+
+
+def rms_norm_dynamic_per_token_quant(result, input, weight, scale, epsilon, scale_ub,
+                                     residual) -> None:
+    # csrc/quantization/fused_kernels/fused_layernorm_dynamic_per_token_quant.cu:132-155
+    _cuda(result, input, weight, scale, scale_ub, residual)
+    if result.dtype == torch.int8:
+        raise RuntimeError("rms_norm_dynamic_per_token_quant: int8 output is outside the fp8 "
+                           "path this library implements")
+    _fp8_out(result)
+    if not input.is_contiguous():
+        raise RuntimeError("input.is_contiguous()")
+    if scale.dtype != torch.float32:
+        raise RuntimeError("scales.dtype() == torch::kFloat32")
+    if residual is not None and not residual.is_contiguous():
+        raise RuntimeError("residual.is_contiguous()")
+    hidden = input.shape[-1]
+    nt = input.numel() // hidden if hidden else 0
+    with _dev(input):
+        check(lib.vllm_amd_rms_norm_dynamic_per_token_quant(
+            _ptr(result), _ptr(input), _ptr(weight), _ptr(scale), float(epsilon), _ptr(scale_ub),
+            _ptr(residual), nt, hidden, _dt(input), _stream(input)))
+
+
+def silu_and_mul_quant(result, input, scale) -> None:
+    # csrc/quantization/activation_kernels.cu:112-121
+    _cuda(result, input, scale)
+    _fp8_out(result)
+    if input.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("input.dtype() == torch::kFloat16 || input.dtype() == torch::kBFloat16")
+    if input.shape[-1] % 2 != 0:
+        raise RuntimeError("input.size(-1) % 2 == 0")
+    if not input.is_contiguous():
+        raise RuntimeError("input.is_contiguous()")
+    d = input.shape[-1] // 2
+    nt = input.numel() // input.shape[-1] if d else 0
+    with _dev(input):
+        check(lib.vllm_amd_silu_and_mul_quant(_ptr(result), _ptr(input), _ptr(scale), nt, d,
+                                              _dt(input), _stream(input)))
+
+
+def compute_slot_mapping(slot_mapping, block_table, req_indices, positions, block_size) -> None:
+    """Device-side BlockTable.compute_slot_mapping (vllm/v1/worker/block_table.py:84-99).
+    Not a reference op: the reference does this with numpy on the host."""
+    _cuda(slot_mapping, block_table, req_indices, positions)
+    assert slot_mapping.dtype == torch.int64 and positions.dtype == torch.int64
+    assert block_table.dtype == torch.int32 and req_indices.dtype == torch.int32
+    assert block_table.is_contiguous() and req_indices.is_contiguous() and positions.is_contiguous()
+    n = req_indices.shape[0]
+    assert slot_mapping.is_contiguous() and slot_mapping.shape[0] >= n and positions.shape[0] >= n
+    with _dev(block_table):
+        check(lib.vllm_amd_compute_slot_mapping(
+            _ptr(slot_mapping), _ptr(block_table), _ptr(req_indices), _ptr(positions), n,
+            block_table.shape[1], block_size, _stream(block_table)))
 
 
 def _quant_common(result, input):
@@ -314,6 +408,21 @@ _SCHEMAS = {
         ("cutlass_scaled_mm",
          "cutlass_scaled_mm(Tensor! out, Tensor a, Tensor b, Tensor a_scales, Tensor b_scales,"
          " Tensor? bias) -> ()", cutlass_scaled_mm),
+        # csrc/torch_bindings.cpp:117-120, 188-211
+        ("silu_and_mul_quant",
+         "silu_and_mul_quant(Tensor! result, Tensor input, Tensor scale) -> ()",
+         silu_and_mul_quant),
+        ("rms_norm_static_fp8_quant",
+         "rms_norm_static_fp8_quant(Tensor! result, Tensor input, Tensor weight, Tensor scale,"
+         " float epsilon) -> ()", rms_norm_static_fp8_quant),
+        ("fused_add_rms_norm_static_fp8_quant",
+         "fused_add_rms_norm_static_fp8_quant(Tensor! result, Tensor input, Tensor! residual,"
+         " Tensor weight, Tensor scale, float epsilon) -> ()",
+         fused_add_rms_norm_static_fp8_quant),
+        ("rms_norm_dynamic_per_token_quant",
+         "rms_norm_dynamic_per_token_quant(Tensor! result, Tensor input, Tensor weight,"
+         " Tensor! scale, float epsilon, Tensor? scale_ub, Tensor!? residual) -> ()",
+         rms_norm_dynamic_per_token_quant),
     ],
     "_C_cache_ops": [
         ("reshape_and_cache",
