@@ -20,7 +20,8 @@ The JSON line also carries
                 from /root/reference/csrc/cpu by oracle/Makefile) on configs[0],
                 timed on the host cores of this box; falls back to our C port
   extra         fp8 scaled_mm TFLOP/s at Llama-3-8B shapes (configs[2]), cache
-                write / quant GB/s, and (N>1) row-parallel GEMM + RCCL all-reduce
+                write / quant / fused-neighbour GB/s, and (N>1) row-parallel GEMM +
+                RCCL all-reduce
 """
 from __future__ import annotations
 
@@ -200,6 +201,49 @@ def run_cache_quant(device, iters=20):
     return out
 
 
+def run_fused_neighbours(device, iters=20):
+    """fused RMSNorm + quant, SiLU-mul + quant, slot mapping.  Algorithmic
+    bytes = every input and output element once (the reference's kernels read the row 2-3x)."""
+    from vllm_amd import _custom_ops as ops, _torch_ops
+    out = {}
+    for M, H in ((64, 4096), (4096, 4096), (4096, 8192)):
+        x = torch.randn((M, H), device=device, dtype=torch.bfloat16)
+        res = torch.randn_like(x)
+        w = torch.ones(H, device=device, dtype=torch.bfloat16)
+        q = torch.empty((M, H), dtype=torch.float8_e4m3fn, device=device)
+        sc = torch.empty((M, 1), dtype=torch.float32, device=device)
+        one = torch.tensor([0.05], device=device)
+        legs = {
+            "rms_norm_dynamic_per_token_quant":
+                (lambda: torch.ops._C.rms_norm_dynamic_per_token_quant(q, x, w, sc, 1e-6, None, None),
+                 M * H * 3 + H * 2 + 4 * M),
+            "rms_norm_dynamic_per_token_quant_residual":
+                (lambda: torch.ops._C.rms_norm_dynamic_per_token_quant(q, x, w, sc, 1e-6, None, res),
+                 M * H * 7 + H * 2 + 4 * M),
+            "fused_add_rms_norm_static_fp8_quant":
+                (lambda: torch.ops._C.fused_add_rms_norm_static_fp8_quant(q, x, res, w, one, 1e-6),
+                 M * H * 7 + H * 2),
+        }
+        for name, (fn, nbytes) in legs.items():
+            t = time_gpu_graph(fn, iters)
+            out[f"{name}_M{M}_H{H}"] = dict(us=round(t * 1e6, 2), gbps=round(nbytes / t / 1e9, 1))
+    for M, d in ((64, 14336), (4096, 14336)):
+        x = torch.randn((M, 2 * d), device=device, dtype=torch.bfloat16)
+        q = torch.empty((M, d), dtype=torch.float8_e4m3fn, device=device)
+        one = torch.tensor([0.05], device=device)
+        t = time_gpu_graph(lambda: torch.ops._C.silu_and_mul_quant(q, x, one), iters)
+        out[f"silu_and_mul_quant_M{M}_d{d}"] = dict(us=round(t * 1e6, 2),
+                                                    gbps=round(M * d * 5 / t / 1e9, 1))
+    R, MB, BS, T = 256, 2048, 16, 8192
+    bt = torch.randint(0, R * MB, (R, MB), dtype=torch.int32, device=device)
+    req = torch.randint(0, R, (T,), dtype=torch.int32, device=device)
+    pos = torch.randint(0, MB * BS, (T,), dtype=torch.int64, device=device)
+    slots = torch.empty(T, dtype=torch.int64, device=device)
+    t = time_gpu_graph(lambda: _torch_ops.compute_slot_mapping(slots, bt, req, pos, BS), iters)
+    out[f"compute_slot_mapping_T{T}"] = dict(us=round(t * 1e6, 2))
+    return out
+
+
 def cpu_baseline():
     """Reference CPU paged_attention_v1 on BASELINE.json configs[0] (32 seqs, ctx 1024,
     32q/8kv, d 128, block 16, bf16 KV), all host cores available to this process."""
@@ -325,11 +369,15 @@ def main():
             extra["scaled_mm_best_tflops"] = best["tflops"]
             extra["scaled_mm_pct_of_fp8_peak"] = round(100 * best["tflops"] / FP8_DENSE_PEAK_TFLOPS, 2)
             extra["cache_quant"] = run_cache_quant(device)
+            extra["fused_neighbours"] = run_fused_neighbours(device)
             line["cpu_baseline"] = cpu_baseline()
         line["extra"] = extra
     if world > 1:
         from vllm_amd.distributed import bench_row_parallel
-        rp = bench_row_parallel(device, dist)
+        try:
+            rp = bench_row_parallel(device, dist)
+        except Exception as e:   # the headline line must still be printed
+            rp = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             line.setdefault("extra", {})["row_parallel_tp"] = rp
         dist.barrier()

@@ -268,7 +268,8 @@ int vllm_amd_swap_blocks(const void* src, void* dst, int64_t block_bytes,
 /*   "mm_kernel":  scaled_mm kernel for M > 32: 0 = heuristic, 1 = register-   */
 /*                 staged 128x128 tile, 2..10 = direct-to-LDS tile shapes       */
 /*                 (256x256, 128x128, 128x64, 64x64, 64x32; even ids 4..10      */
-/*                 take 2 or 4 K blocks per barrier; scaled_mm_large.hip)       */
+/*                 take 2 or 4 K blocks per barrier; scaled_mm_large.hip),      */
+/*                 11 = weight-streaming kernel (M <= 32 only)                  */
 /* ------------------------------------------------------------------------- */
 int vllm_amd_set_tuning(const char* key, int value);
 

@@ -94,9 +94,9 @@ def force_kernel():
     _lib.set_tuning("mm_kernel", 0)
 
 
-@pytest.mark.parametrize("kernel", list(range(1, 11)))
+@pytest.mark.parametrize("kernel", list(range(1, 12)))
 @pytest.mark.parametrize("MNK", [(300, 520, 256), (256, 256, 1024), (257, 971, 384), (640, 1288, 2048),
-                                 (40, 8, 128 * 3)])
+                                 (40, 8, 128 * 3), (5, 264, 512), (32, 1040, 1024)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
 def test_scaled_mm_every_tile_kernel(ops, oracle, force_kernel, kernel, MNK, out_dtype):
     """The auto dispatch picks a tile shape from the problem size; force each one on ragged small shapes (edge tiles, odd N -> scalar epilogue,

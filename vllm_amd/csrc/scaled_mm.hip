@@ -292,7 +292,14 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
              op);
   VA_REQUIRE((a_scale_numel == 1 || a_scale_numel == M) && (b_scale_numel == 1 || b_scale_numel == N),
              VLLM_AMD_EINVAL, "%s: scales must be per-tensor or per-row/per-column", op);
-  if (M <= 32) {
+  const bool glds_ok = K % 128 == 0 && K >= 256 && scaled_mm_large_fits(M, N, K, lda, ldb);
+  // M <= 32: the weight-streaming kernel (one workgroup per 16 output columns) wins while
+  // its grid is a single wave of workgroups and M fits one MFMA tile; beyond that the
+  // 64x32 direct-to-LDS tile is flat in M and faster (profiles/r01_gemm_sweep_small.csv).
+  // "mm_kernel" 11 forces it.
+  const bool skinny = g_mm_kernel == 11 ||
+                      (g_mm_kernel == 0 && (!glds_ok || (M <= 16 && ceil_div(N, 16) <= 256)));
+  if (M <= 32 && skinny) {
     const int mt = ceil_div(M, 16);
 #define SK(T, MT)                                                                              \
   hipLaunchKernelGGL((scaled_mm_skinny_kernel<T, MT>), dim3(ceil_div(N, 16)),                  \
@@ -312,9 +319,9 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
   }
   const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
   const bool vec = (ldc % 4 == 0) && ((((uintptr_t)out) & 7) == 0);
-  if (K % 128 == 0 && K >= 256 && scaled_mm_large_fits(M, N, K, lda, ldb)) {
+  if (glds_ok) {
     int sel = g_mm_kernel;
-    if (sel == 0) {
+    if (sel == 0 || sel > 10) {
       // Largest tile that still yields ~3/4 of a full wave of workgroups (256 CUs); rows of
       // a tile beyond M are wasted MFMA work, so BM <= 2 M.  With >= 1.5 waves of tiles the
       // variant that fits several workgroups per CU wins, below that the variant that takes

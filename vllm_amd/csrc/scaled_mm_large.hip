@@ -60,13 +60,16 @@ __device__ __forceinline__ void lds_read_frag(uint32_t a0, uint32_t a1, i32x4& l
   hi = lds_read16<BASE + T * 16 * LBK>(a1);
 }
 
-template <int BASE, int T0, int NT>
-__device__ __forceinline__ void read_w(uint32_t a0, uint32_t a1, i32x4 (&lo)[NT], i32x4 (&hi)[NT]) {
-  lds_read_frag<BASE, 0>(a0, a1, lo[0], hi[0]);
-  if constexpr (NT > 1) lds_read_frag<BASE, 1>(a0, a1, lo[1], hi[1]);
+// first reads of a K block, in the order its MFMAs consume them: W0, A0, W1 .. W(NT-1)
+template <int BASE, int NT>
+__device__ __forceinline__ void block_start(uint32_t w0, uint32_t w1, uint32_t a0, uint32_t a1,
+                                            i32x4 (&wl)[NT], i32x4 (&wh)[NT], i32x4& al, i32x4& ah) {
+  lds_read_frag<BASE, 0>(w0, w1, wl[0], wh[0]);
+  lds_read_frag<BASE, 0>(a0, a1, al, ah);
+  if constexpr (NT > 1) lds_read_frag<BASE, 1>(w0, w1, wl[1], wh[1]);
   if constexpr (NT > 2) {
-    lds_read_frag<BASE, 2>(a0, a1, lo[2], hi[2]);
-    lds_read_frag<BASE, 3>(a0, a1, lo[3], hi[3]);
+    lds_read_frag<BASE, 2>(w0, w1, wl[2], wh[2]);
+    lds_read_frag<BASE, 3>(w0, w1, wl[3], wh[3]);
   }
 }
 
@@ -74,23 +77,13 @@ __device__ __forceinline__ void read_w(uint32_t a0, uint32_t a1, i32x4 (&lo)[NT]
 // fragments pass through the asm as in/out operands, so their consumers stay behind it.
 template <int LATER>
 __device__ __forceinline__ void wait_frag(i32x4& a0, i32x4& a1) {
+  static_assert(LATER <= 15, "lgkmcnt is 4 bits");
   asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(a0), "+v"(a1) : [n] "n"(LATER));
 }
-
-template <int LATER, int NT>
-__device__ __forceinline__ void wait_frags(i32x4 (&wl)[NT], i32x4 (&wh)[NT], i32x4& a0, i32x4& a1) {
+template <int LATER>
+__device__ __forceinline__ void wait_wa(i32x4& w0, i32x4& w1, i32x4& a0, i32x4& a1) {
   static_assert(LATER <= 15, "lgkmcnt is 4 bits");
-  if constexpr (NT == 4)
-    asm volatile("s_waitcnt lgkmcnt(%[n])"
-                 : "+v"(wl[0]), "+v"(wh[0]), "+v"(wl[1]), "+v"(wh[1]), "+v"(wl[2]), "+v"(wh[2]),
-                   "+v"(wl[3]), "+v"(wh[3]), "+v"(a0), "+v"(a1)
-                 : [n] "n"(LATER));
-  else if constexpr (NT == 2)
-    asm volatile("s_waitcnt lgkmcnt(%[n])"
-                 : "+v"(wl[0]), "+v"(wh[0]), "+v"(wl[1]), "+v"(wh[1]), "+v"(a0), "+v"(a1)
-                 : [n] "n"(LATER));
-  else
-    asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(wl[0]), "+v"(wh[0]), "+v"(a0), "+v"(a1) : [n] "n"(LATER));
+  asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(w0), "+v"(w1), "+v"(a0), "+v"(a1) : [n] "n"(LATER));
 }
 
 template <typename F, int... I>
@@ -213,43 +206,61 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
     if (g + NST - 1 <= ng) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * KB * LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (g + NST - 1 < ng) group_load(nxt, g + NST - 1);
 
     const uint32_t so = cur * (KB * STAGE);
-    nxt = cur;
-    cur = cur + 1 == NST ? 0 : cur + 1;
     const uint32_t wa0 = w_addr[0] + so, wa1 = w_addr[1] + so;
     const uint32_t aa0 = a_addr[0] + so, aa1 = a_addr[1] + so;
 
     // Software pipeline over the KB * MT steps (kb, mt) of the group, fully unrolled: the
     // fragments of step s+1 are requested before the MFMAs of step s, and every wait counts
-    // exactly the reads issued after the ones it needs.
+    // exactly the reads issued after the ones it needs.  A block starts with the reads
+    // W0, A0, W1 .. W(NT-1): its first MFMA waits for 4 reads, not for all of them.
+    static_assert(MT >= 2, "the wait counts below assume a block has >= 2 m-steps");
     i32x4 wl[2][NT], wh[2][NT];   // weight fragments of block kb in [kb & 1]
     i32x4 al[2], ah[2];           // activation fragment of step s in [s & 1]
     i32x8 wf[NT];
-    read_w<0, 0>(wa0, wa1, wl[0], wh[0]);
-    lds_read_frag<0, 0>(aa0, aa1, al[0], ah[0]);
+    block_start<0>(wa0, wa1, aa0, aa1, wl[0], wh[0], al[0], ah[0]);
+    // the refill is issued behind the first fragment reads: they are what the MFMAs wait for
+    if (g + NST - 1 < ng) group_load(nxt, g + NST - 1);
+    nxt = cur;
+    cur = cur + 1 == NST ? 0 : cur + 1;
     static_for<KB * MT>([&](auto ic) {
       constexpr int s = decltype(ic)::value;
       constexpr int kb = s / MT, mt = s % MT;
       constexpr int s1 = s + 1, kb1 = s1 / MT, mt1 = s1 % MT;
       constexpr bool more = s1 < KB * MT;
-      constexpr bool next_w = more && mt1 == 0;
-      if constexpr (next_w) read_w<kb1 * STAGE, 0>(wa0, wa1, wl[kb1 & 1], wh[kb1 & 1]);
-      if constexpr (more) lds_read_frag<kb1 * STAGE, mt1>(aa0, aa1, al[s1 & 1], ah[s1 & 1]);
-      constexpr int later = (more ? 2 : 0) + (next_w ? 2 * NT : 0);
+      constexpr bool next_block = more && mt1 == 0;   // only at mt == MT-1 >= 1
+      if constexpr (next_block)
+        block_start<kb1 * STAGE>(wa0, wa1, aa0, aa1, wl[kb1 & 1], wh[kb1 & 1], al[s1 & 1], ah[s1 & 1]);
+      else if constexpr (more)
+        lds_read_frag<kb1 * STAGE, mt1>(aa0, aa1, al[s1 & 1], ah[s1 & 1]);
+      constexpr int later = next_block ? 2 + 2 * NT : (more ? 2 : 0);
       if constexpr (mt == 0) {
-        wait_frags<later>(wl[kb & 1], wh[kb & 1], al[s & 1], ah[s & 1]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wf[nt] = cat8(wl[kb & 1][nt], wh[kb & 1][nt]);
+        // reads of this block in issue order: W0 A0 W1 .. W(NT-1), then `later` younger ones
+        wait_wa<later + 2 * (NT - 1)>(wl[kb & 1][0], wh[kb & 1][0], al[s & 1], ah[s & 1]);
+        const i32x8 af = cat8(al[s & 1], ah[s & 1]);
+        wf[0] = cat8(wl[kb & 1][0], wh[kb & 1][0]);
+        acc[0][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+            wf[0], af, acc[0][mt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        // keep each MFMA above the next wait (the scheduler would sink all of them below
+        // the last one and the early start would be lost)
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NT - 1>([&](auto jc) {
+          constexpr int nt = decltype(jc)::value + 1;
+          wait_frag<later + 2 * (NT - 1 - nt)>(wl[kb & 1][nt], wh[kb & 1][nt]);
+          wf[nt] = cat8(wl[kb & 1][nt], wh[kb & 1][nt]);
+          acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+              wf[nt], af, acc[nt][mt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          __builtin_amdgcn_sched_barrier(0);
+        });
       } else {
         wait_frag<later>(al[s & 1], ah[s & 1]);
-      }
-      const i32x8 af = cat8(al[s & 1], ah[s & 1]);
+        const i32x8 af = cat8(al[s & 1], ah[s & 1]);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-            wf[nt], af, acc[nt][mt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+              wf[nt], af, acc[nt][mt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
     });
   }
 
