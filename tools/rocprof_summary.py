@@ -15,10 +15,10 @@ def main():
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
-                agg[(r["Kernel_Name"][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
+                agg[(r["Kernel_Name"][:72], r["Counter_Name"])].append(float(r["Counter_Value"]))
             print("== PMC (rocprofv3 --pmc):", d)
             for (k, c), v in sorted(agg.items()):
-                if "va::" not in k:
+                if "va::" not in k and "_ZN2va" not in k:
                     continue
                 avg = sum(v) / len(v)
                 extra = ""
@@ -26,7 +26,8 @@ def main():
                     extra = f"  -> x2 (gfx950 correction) = {avg * 2 * 1024 / 1e6:.1f} MB read / launch"
                 if c == "WRITE_SIZE":
                     extra = f"  -> {avg * 1024 / 1e6:.2f} MB written / launch"
-                print(f"  {c:12s} n={len(v):3d} avg={avg:14.1f} (KB){extra}   {k}")
+                unit = "(KB)" if c in ("FETCH_SIZE", "WRITE_SIZE") else ""
+                print(f"  {c:24s} n={len(v):3d} avg={avg:14.1f} {unit}{extra}   {k}")
 
 if __name__ == "__main__":
     main()
