@@ -258,6 +258,36 @@ int vllm_amd_swap_blocks(const void* src, void* dst, int64_t block_bytes,
                          const int64_t* block_mapping_host, int64_t num_pairs,
                          void* stream);
 
+/* Replaces context_attention_fwd (vllm/attention/ops/prefix_prefill.py:726-913; Triton
+ * kernels _fwd_kernel :36-288, _fwd_kernel_alibi :477-722): prefill / chunked-prefill
+ * attention.  For sequence b the query tokens q[b_start_loc[b] : b_start_loc[b+1]] (positions
+ * ctx .. seq_len-1, ctx = b_seq_len[b] - query_len) attend to the ctx cached tokens in the
+ * paged cache (through b_loc[b, :], no causal mask) and to the new tokens' dense k / v
+ * (causal), one softmax over both; out = acc / l.
+ *   q, o    [num_tokens, num_heads, head_size]; k, v [num_tokens, num_kv_heads, head_size]
+ *           (element strides *_stride_t per token, *_stride_h per head; head dim contiguous)
+ *   caches  as paged_attention_v1 (element strides of dim 0 and 1)
+ *   b_loc   int32 [batch, *] block table (row stride b_loc_stride), b_start_loc int32
+ *           [batch+1], b_seq_len int32 [batch]
+ *   k_scale, v_scale  float[1], fp8 cache only: k = (fp8 -> f32 * k_scale).to(q dtype)
+ *   alibi_slopes      float[num_heads] or NULL (with ALiBi the sliding window is ignored,
+ *                     as in the reference's alibi kernel)
+ *   fp8_out_scale     float[1] or NULL: o is e4m3 bytes = clamp(acc / l / scale)
+ *   sliding_window    <= 0 disables; skip_decode: sequences with one query token are skipped
+ * Supported here: f16 / bf16 queries, head_size 32/64/96/128, block_size 16/32,
+ * kv_cache_dtype auto / fp8_e4m3. */
+int vllm_amd_context_attention_fwd(
+    void* o, const void* q, const void* k, const void* v, const void* k_cache,
+    const void* v_cache, const int* b_loc, const int* b_start_loc,
+    const int* b_seq_len, const float* k_scale, const float* v_scale,
+    const float* alibi_slopes, const float* fp8_out_scale, int batch, int num_heads,
+    int num_kv_heads, int head_size, int block_size, int max_input_len,
+    int64_t b_loc_stride, int64_t q_stride_t, int64_t q_stride_h, int64_t k_stride_t,
+    int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, int64_t o_stride_t,
+    int64_t o_stride_h, int64_t kc_block_stride, int64_t kc_head_stride,
+    int64_t vc_block_stride, int64_t vc_head_stride, float sm_scale, int sliding_window,
+    int skip_decode, int dtype, int kv_cache_dtype, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Tuning knobs (no counterpart in the reference): used by tools/ and bench   */
 /* scripts to A/B kernel variants inside one process.                          */

@@ -797,3 +797,98 @@ void oracle_compute_slot_mapping(int64_t* slot_mapping, const int32_t* block_tab
     slot_mapping[i] = (int64_t)block_table[bi] * block_size + positions[i] % block_size;
   }
 }
+
+/* ------------------------------------------------------------------ */
+/* prefill attention with a paged prefix              */
+/* ------------------------------------------------------------------ */
+/* vllm/attention/ops/prefix_prefill.py:36-288 (_fwd_kernel) and :477-722
+ * (_fwd_kernel_alibi), restated per (sequence, head, query row): scores in fp32 over the
+ * cached context (no causal mask; fp8 context dequantised as (fp8 * scale).to(dtype),
+ * :168-169, :212-213) and over the new tokens (causal), sliding window -> -10000 (:190-192),
+ * ALiBi bias where <= 0 (:603-608), p rounded to the value dtype before P.V (:216),
+ * out = acc / l (:276), optional fp8 output (:282-284).  The reference rounds p against the
+ * RUNNING maximum of its tile order; here the final maximum is used (the difference is
+ * below the rounding of p itself). */
+void oracle_context_attention_fwd(
+    void* o, const void* q, const void* k, const void* v, const void* k_cache,
+    const void* v_cache, const int32_t* b_loc, const int32_t* b_start_loc,
+    const int32_t* b_seq_len, float k_scale, float v_scale, const float* alibi_slopes,
+    const float* fp8_out_scale, int batch, int num_heads, int num_kv_heads, int head_size,
+    int block_size, int x, int64_t b_loc_stride, int64_t q_stride_t, int64_t q_stride_h,
+    int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
+    int64_t o_stride_t, int64_t o_stride_h, int64_t kc_block_stride, int64_t kc_head_stride,
+    int64_t vc_block_stride, int64_t vc_head_stride, float sm_scale, int sliding_window,
+    int skip_decode, int dt, int kv_dt) {
+  const int D = head_size, BS = block_size;
+  const int gq = num_heads / num_kv_heads;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int b = 0; b < batch; ++b)
+    for (int h = 0; h < num_heads; ++h) {
+      const int tok0 = b_start_loc[b], qlen = b_start_loc[b + 1] - tok0;
+      const int seq_len = b_seq_len[b], ctx = seq_len - qlen, kvh = h / gq;
+      if (skip_decode && qlen == 1) continue;
+      const int total = ctx + qlen;
+      float* kf = (float*)malloc(sizeof(float) * (size_t)total * D);
+      float* vf = (float*)malloc(sizeof(float) * (size_t)total * D);
+      float* sc = (float*)malloc(sizeof(float) * (size_t)total);
+      for (int n = 0; n < ctx; ++n) {
+        const int64_t blk = b_loc[b * b_loc_stride + n / BS];
+        const int off = n % BS;
+        for (int d = 0; d < D; ++d) {
+          const int64_t ki = blk * kc_block_stride + kvh * kc_head_stride +
+                             (int64_t)(d / x) * BS * x + (int64_t)off * x + d % x;
+          const int64_t vi = blk * vc_block_stride + kvh * vc_head_stride + (int64_t)d * BS + off;
+          if (kv_dt == KV_FP8_E4M3) {
+            kf[(size_t)n * D + d] = round_to(oracle_fp8_e4m3_to_f32(((const uint8_t*)k_cache)[ki]) * k_scale, dt);
+            vf[(size_t)n * D + d] = round_to(oracle_fp8_e4m3_to_f32(((const uint8_t*)v_cache)[vi]) * v_scale, dt);
+          } else {
+            kf[(size_t)n * D + d] = load_as_f32(k_cache, ki, dt);
+            vf[(size_t)n * D + d] = load_as_f32(v_cache, vi, dt);
+          }
+        }
+      }
+      for (int n = 0; n < qlen; ++n)
+        for (int d = 0; d < D; ++d) {
+          kf[(size_t)(ctx + n) * D + d] = load_as_f32(k, (tok0 + n) * k_stride_t + kvh * k_stride_h + d, dt);
+          vf[(size_t)(ctx + n) * D + d] = load_as_f32(v, (tok0 + n) * v_stride_t + kvh * v_stride_h + d, dt);
+        }
+      const int window = alibi_slopes ? 0 : sliding_window;
+      for (int m = 0; m < qlen; ++m) {
+        const int qpos = ctx + m;
+        float mx = -INFINITY;
+        for (int n = 0; n <= qpos; ++n) {   /* context: all; new: causal */
+          float acc = 0.f;
+          for (int d = 0; d < D; ++d)
+            acc += load_as_f32(q, (tok0 + m) * q_stride_t + h * q_stride_h + d, dt) * kf[(size_t)n * D + d];
+          float s = acc * sm_scale;
+          if (alibi_slopes) {
+            float bias = (float)(n - qpos) * alibi_slopes[h];
+            s = (bias <= 0.f && qpos < seq_len) ? s + bias : -INFINITY;
+          } else if (window > 0 && qpos - n >= window) {
+            s = -10000.0f;
+          }
+          sc[n] = s;
+          mx = fmaxf(mx, s);
+        }
+        float l = 0.f;
+        double acc[256];
+        for (int d = 0; d < D; ++d) acc[d] = 0;
+        for (int n = 0; n <= qpos; ++n) {
+          float p = expf(sc[n] - mx);
+          l += p;
+          float pr = round_to(p, dt);
+          for (int d = 0; d < D; ++d) acc[d] += (double)pr * vf[(size_t)n * D + d];
+        }
+        for (int d = 0; d < D; ++d) {
+          float y = (float)acc[d] / l;
+          if (fp8_out_scale) {
+            float z = fmaxf(-FP8_MAX, fminf(y / *fp8_out_scale, FP8_MAX));
+            ((uint8_t*)o)[(tok0 + m) * o_stride_t + h * o_stride_h + d] = oracle_f32_to_fp8_e4m3(z);
+          } else {
+            store_from_f32(o, (tok0 + m) * o_stride_t + h * o_stride_h + d, dt, y);
+          }
+        }
+      }
+      free(kf); free(vf); free(sc);
+    }
+}

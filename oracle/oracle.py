@@ -311,3 +311,28 @@ def compute_slot_mapping(block_table, req_indices, positions, block_size: int) -
                                       _p(req_indices.contiguous()), _p(positions.contiguous()),
                                       _i64(n), block_table.shape[1], block_size)
     return out
+
+
+# vllm/attention/ops/prefix_prefill.py:726-913
+def context_attention_fwd(q, k, v, o, kv_cache_dtype, k_cache, v_cache, b_loc, b_start_loc,
+                          b_seq_len, max_seq_len, max_input_len, k_scale, v_scale,
+                          alibi_slopes=None, sliding_window=None, sm_scale=None,
+                          skip_decode=False, fp8_out_scale=None) -> None:
+    if sm_scale is None:
+        sm_scale = 1.0 / (q.shape[-1] ** 0.5)
+    if sliding_window is None or sliding_window <= 0:
+        sliding_window = 0
+    b_loc = b_loc.to(torch.int32).contiguous()
+    b_start_loc = b_start_loc.to(torch.int32).contiguous()
+    b_seq_len = b_seq_len.to(torch.int32).contiguous()
+    slopes = None if alibi_slopes is None else alibi_slopes.float().contiguous()
+    fo = None if fp8_out_scale is None else fp8_out_scale.float().reshape(1).contiguous()
+    lib().oracle_context_attention_fwd(
+        _p(o), _p(q), _p(k), _p(v), _p(k_cache), _p(v_cache), _p(b_loc), _p(b_start_loc),
+        _p(b_seq_len), _f(k_scale), _f(v_scale), _p(slopes), _p(fo), b_seq_len.shape[0],
+        q.shape[1], k.shape[1], q.shape[2], v_cache.shape[3], k_cache.shape[4],
+        _i64(b_loc.stride(0)), _i64(q.stride(0)), _i64(q.stride(1)), _i64(k.stride(0)),
+        _i64(k.stride(1)), _i64(v.stride(0)), _i64(v.stride(1)), _i64(o.stride(0)),
+        _i64(o.stride(1)), _i64(k_cache.stride(0)), _i64(k_cache.stride(1)),
+        _i64(v_cache.stride(0)), _i64(v_cache.stride(1)), _f(sm_scale), int(sliding_window),
+        int(bool(skip_decode)), DT[q.dtype], _kv(kv_cache_dtype))

@@ -70,3 +70,89 @@ def codes_close(a, b, max_frac):
     adj = ((a - b).abs() == 1) | ((a & 0x7f) + (b & 0x7f) <= 1)
     assert bool((diff & ~adj).sum() == 0), "codes differ by more than one step"
     assert diff.float().mean().item() <= max_frac, f"{int(diff.sum())} of {diff.numel()} codes differ"
+
+
+def make_prefill_case(query_lens, ctx_lens, H, KVH, D, BS, dtype, kv_cache_dtype="auto", seed=0,
+                      kv_scale=1.0, amp=1.0):
+    """Inputs of context_attention_fwd built like the reference test
+    (tests/kernels/attention/test_prefix_prefill.py:66-153): per sequence ctx cached tokens in a
+    paged cache (random distinct blocks) + query_len new tokens in dense k / v.  Returns CPU
+    tensors plus `key_full`/`value_full` (per-sequence dense K/V as the kernel sees them, i.e.
+    context dequantised) for torch reference checks."""
+    g = torch.Generator().manual_seed(seed)
+    B = len(query_lens)
+    seq_lens = [a + b for a, b in zip(query_lens, ctx_lens)]
+    T = sum(query_lens)
+    q = ((torch.rand((T, H, D), generator=g) * 2 - 1) * amp).to(dtype)
+    k = ((torch.rand((T, KVH, D), generator=g) * 2 - 1) * amp).to(dtype)
+    v = ((torch.rand((T, KVH, D), generator=g) * 2 - 1) * amp).to(dtype)
+    max_blocks = max((c + BS - 1) // BS for c in ctx_lens) + 2
+    NB = B * max_blocks + 3
+    perm = torch.randperm(NB, generator=g)
+    b_loc = perm[: B * max_blocks].view(B, max_blocks).to(torch.int32)
+    fp8 = kv_cache_dtype != "auto"
+    x = 16 if fp8 else 8
+    cdt = torch.uint8 if fp8 else dtype
+    # stale contents everywhere (incl. NaN patterns) so that masking of tokens >= ctx is tested
+    if fp8:
+        k_cache = torch.randint(0, 256, (NB, KVH, D // x, BS, x), generator=g, dtype=torch.uint8)
+        v_cache = torch.randint(0, 256, (NB, KVH, D, BS), generator=g, dtype=torch.uint8)
+    else:
+        k_cache = torch.full((NB, KVH, D // x, BS, x), float("nan"), dtype=dtype)
+        v_cache = torch.full((NB, KVH, D, BS), float("nan"), dtype=dtype)
+    ctx_k, ctx_v = [], []
+    for b in range(B):
+        c = ctx_lens[b]
+        ck = ((torch.rand((c, KVH, D), generator=g) * 2 - 1) * amp).to(dtype)
+        cv = ((torch.rand((c, KVH, D), generator=g) * 2 - 1) * amp).to(dtype)
+        if fp8:
+            ck8 = (ck.float() / kv_scale).clamp(-448, 448).to(torch.float8_e4m3fn)
+            cv8 = (cv.float() / kv_scale).clamp(-448, 448).to(torch.float8_e4m3fn)
+            ck = (ck8.float() * kv_scale).to(dtype)
+            cv = (cv8.float() * kv_scale).to(dtype)
+            ckw, cvw = ck8.view(torch.uint8), cv8.view(torch.uint8)
+        else:
+            ckw, cvw = ck, cv
+        for n in range(c):
+            blk, off = int(b_loc[b, n // BS]), n % BS
+            k_cache[blk, :, :, off, :] = ckw[n].view(KVH, D // x, x)
+            v_cache[blk, :, :, off] = cvw[n]
+        ctx_k.append(ck)
+        ctx_v.append(cv)
+    b_start_loc = torch.tensor([0] + list(torch.tensor(query_lens).cumsum(0)), dtype=torch.int32)
+    b_seq_len = torch.tensor(seq_lens, dtype=torch.int32)
+    key_full, value_full = [], []
+    for b in range(B):
+        s, e = int(b_start_loc[b]), int(b_start_loc[b + 1])
+        key_full.append(torch.cat([ctx_k[b], k[s:e]], 0))
+        value_full.append(torch.cat([ctx_v[b], v[s:e]], 0))
+    return dict(q=q, k=k, v=v, k_cache=k_cache, v_cache=v_cache, b_loc=b_loc,
+                b_start_loc=b_start_loc, b_seq_len=b_seq_len, max_input_len=max(query_lens),
+                max_seq_len=max(seq_lens), key_full=key_full, value_full=value_full,
+                query_lens=query_lens, ctx_lens=ctx_lens, scale=torch.tensor([kv_scale]))
+
+
+def prefill_reference(c, sliding_window=0, alibi_slopes=None, sm_scale=None):
+    """fp32 torch attention with the bottom-right causal (+ local) mask the reference test
+    builds with xformers (test_prefix_prefill.py:195-212)."""
+    q = c["q"].float()
+    T, H, D = q.shape
+    KVH = c["k"].shape[1]
+    sm_scale = sm_scale or D ** -0.5
+    out = torch.empty_like(q)
+    for b, (ql, cl) in enumerate(zip(c["query_lens"], c["ctx_lens"])):
+        s = int(c["b_start_loc"][b])
+        kf = c["key_full"][b].float().repeat_interleave(H // KVH, dim=1)   # [L, H, D]
+        vf = c["value_full"][b].float().repeat_interleave(H // KVH, dim=1)
+        L = cl + ql
+        sc = torch.einsum("mhd,nhd->hmn", q[s:s + ql], kf) * sm_scale
+        qpos = torch.arange(cl, L, device=q.device).view(1, ql, 1)
+        kpos = torch.arange(L, device=q.device).view(1, 1, L)
+        mask = kpos <= qpos
+        if alibi_slopes is not None:
+            sc = sc + (kpos - qpos).float() * alibi_slopes.to(q.device).view(H, 1, 1)
+        elif sliding_window > 0:
+            mask = mask & (qpos - kpos < sliding_window)
+        sc = sc.masked_fill(~mask, float("-inf"))
+        out[s:s + ql] = torch.einsum("hmn,nhd->mhd", sc.softmax(-1), vf)
+    return out

@@ -1,0 +1,137 @@
+"""GPU parity: prefill / chunked-prefill attention with a paged prefix
+(`context_attention_fwd`, C ABI `vllm_amd_context_attention_fwd`) against the CPU oracle and
+against an fp32 torch attention (the check of the reference's own test,
+tests/kernels/attention/test_prefix_prefill.py:195-232).
+
+Stated tolerance: the reference test allows atol 1e-4 (auto) / 1e-3 (fp8) on inputs of
+amplitude 1e-3; here inputs have amplitude 1 (outputs O(1)), and the bound is the rounding of
+the probabilities to the value dtype: atol 1.5e-3 (fp16) / 6e-3 (bf16), rtol 0, against both
+the oracle and the fp32 torch reference.
+"""
+import pytest
+import torch
+
+from helpers import make_prefill_case, prefill_reference
+
+pytestmark = pytest.mark.gpu
+
+
+def run(c, kv, dev_extra=None, **kw):
+    from vllm_amd.attention.ops import context_attention_fwd
+    o = torch.zeros_like(c["q"]).cuda() if kw.get("fp8_out_scale") is None else \
+        torch.zeros(c["q"].shape, dtype=torch.uint8).cuda()
+    sc = c["scale"].cuda()
+    context_attention_fwd(c["q"].cuda(), c["k"].cuda(), c["v"].cuda(), o, kv, c["k_cache"].cuda(),
+                          c["v_cache"].cuda(), c["b_loc"].cuda(), c["b_start_loc"].cuda(),
+                          c["b_seq_len"].cuda(), c["max_seq_len"], c["max_input_len"], sc, sc, **kw)
+    return o.cpu()
+
+
+def run_oracle(oracle, c, kv, **kw):
+    o = torch.zeros_like(c["q"]) if kw.get("fp8_out_scale") is None else \
+        torch.zeros(c["q"].shape, dtype=torch.uint8)
+    oracle.context_attention_fwd(c["q"], c["k"], c["v"], o, kv, c["k_cache"], c["v_cache"],
+                                 c["b_loc"], c["b_start_loc"], c["b_seq_len"], c["max_seq_len"],
+                                 c["max_input_len"], float(c["scale"]), float(c["scale"]), **kw)
+    return o
+
+
+def tol(dtype):
+    return 6e-3 if dtype == torch.bfloat16 else 1.5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("head_size", [128, 64, 96, 32])
+@pytest.mark.parametrize("block_size", [16, 32])
+@pytest.mark.parametrize("gqa", [1, 4])
+def test_prefill_shapes(oracle, dtype, kv, head_size, block_size, gqa):
+    """Ragged batch: a decode-like sequence (1 query token), a pure prefill (no context), a
+    chunked prefill whose lengths straddle tile boundaries, and a block-multiple one."""
+    H = 4
+    c = make_prefill_case([1, 150, 77, 128], [200, 0, 131, 64], H, H // gqa, head_size, block_size,
+                          dtype, kv, seed=head_size + block_size + gqa, kv_scale=0.02)
+    out = run(c, kv)
+    assert not out.isnan().any()
+    torch.testing.assert_close(out.float(), run_oracle(oracle, c, kv).float(), atol=tol(dtype), rtol=0)
+    torch.testing.assert_close(out.float(), prefill_reference(c), atol=tol(dtype), rtol=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("window", [16, 64, 128, 512])   # test_prefix_prefill.py:28
+def test_prefill_sliding_window(oracle, dtype, kv, window):
+    c = make_prefill_case([1, 200, 90], [150, 40, 300], 4, 2, 128, 16, dtype, kv, seed=window,
+                          kv_scale=0.02)
+    out = run(c, kv, sliding_window=window)
+    torch.testing.assert_close(out.float(), run_oracle(oracle, c, kv, sliding_window=window).float(),
+                               atol=tol(dtype), rtol=0)
+    torch.testing.assert_close(out.float(), prefill_reference(c, window), atol=tol(dtype), rtol=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+def test_prefill_alibi(oracle, dtype, kv):
+    H = 8
+    slopes = torch.tensor([2.0 ** -(i + 1) for i in range(H)])
+    c = make_prefill_case([1, 140, 60], [100, 33, 260], H, 2, 128, 16, dtype, kv, seed=11,
+                          kv_scale=0.02)
+    out = run(c, kv, alibi_slopes=slopes.cuda(), sliding_window=64)   # window ignored with alibi
+    ref = run_oracle(oracle, c, kv, alibi_slopes=slopes, sliding_window=64)
+    torch.testing.assert_close(out.float(), ref.float(), atol=tol(dtype), rtol=0)
+    torch.testing.assert_close(out.float(), prefill_reference(c, 0, slopes), atol=tol(dtype), rtol=0)
+
+
+def test_prefill_skip_decode_and_strides(oracle):
+    """skip_decode leaves single-token sequences untouched (:104-105); q / k / v / o may be
+    strided views (qkv slices of one projection output)."""
+    H, KVH, D = 4, 2, 128
+    c = make_prefill_case([1, 70, 1, 33], [50, 20, 9, 0], H, KVH, D, 16, torch.bfloat16, "auto", seed=5)
+    T = c["q"].shape[0]
+    qkv = torch.zeros((T, (H + 2 * KVH) * D), dtype=torch.bfloat16)
+    qkv[:, : H * D] = c["q"].reshape(T, -1)
+    qkv[:, H * D:(H + KVH) * D] = c["k"].reshape(T, -1)
+    qkv[:, (H + KVH) * D:] = c["v"].reshape(T, -1)
+    qkv = qkv.cuda()
+    from vllm_amd.attention.ops import context_attention_fwd
+    o = torch.full((T, H, D), 7.0, dtype=torch.bfloat16, device="cuda")
+    one = torch.ones(1, device="cuda")
+    context_attention_fwd(qkv[:, : H * D].view(T, H, D), qkv[:, H * D:(H + KVH) * D].view(T, KVH, D),
+                          qkv[:, (H + KVH) * D:].view(T, KVH, D), o, "auto", c["k_cache"].cuda(),
+                          c["v_cache"].cuda(), c["b_loc"].cuda(), c["b_start_loc"].cuda(),
+                          c["b_seq_len"].cuda(), c["max_seq_len"], c["max_input_len"], one, one,
+                          skip_decode=True)
+    ref = prefill_reference(c)
+    o = o.cpu().float()
+    for b, ql in enumerate(c["query_lens"]):
+        s = int(c["b_start_loc"][b])
+        if ql == 1:
+            assert bool((o[s] == 7.0).all())
+        else:
+            torch.testing.assert_close(o[s:s + ql], ref[s:s + ql], atol=6e-3, rtol=0)
+
+
+def test_prefill_fp8_output(oracle):
+    """fp8_out_scale: e4m3 output = clamp(acc / l / scale) (:282-287).  Compared after
+    dequantisation: the attention tolerance plus one e4m3 step (2^-3 relative) where the
+    6e-3 difference straddles a rounding boundary; and exactly saturated where it must be."""
+    c = make_prefill_case([100, 40], [64, 10], 4, 4, 128, 16, torch.bfloat16, "fp8", seed=2, kv_scale=0.02)
+    fs = torch.tensor([0.01])
+    out = run(c, "fp8", fp8_out_scale=fs.cuda())
+    ref = run_oracle(oracle, c, "fp8", fp8_out_scale=fs)
+    dec = lambda t: t.view(torch.float8_e4m3fn).float() * 0.01
+    assert not dec(out).isnan().any()
+    torch.testing.assert_close(dec(out), dec(ref), atol=8e-3, rtol=0.13)
+    full = prefill_reference(c)
+    torch.testing.assert_close(dec(out), full.clamp(-4.48, 4.48), atol=8e-3, rtol=0.13)
+
+
+def test_prefill_large_matches_torch():
+    """configs-sized chunk (2048 new tokens over a 2048-token fp8 prefix, 8 q / 2 kv heads) vs the
+    fp32 torch reference on the GPU (no oracle: size-independent check of the tiling)."""
+    c = make_prefill_case([2048, 333], [2048, 1000], 8, 2, 128, 16, torch.bfloat16, "fp8", seed=9,
+                          kv_scale=0.02)
+    out = run(c, "fp8")
+    ref = prefill_reference({k: ([t.cuda() for t in v] if isinstance(v, list) and torch.is_tensor(v[0])
+                                 else (v.cuda() if torch.is_tensor(v) else v)) for k, v in c.items()})
+    torch.testing.assert_close(out.float(), ref.cpu(), atol=6e-3, rtol=0)

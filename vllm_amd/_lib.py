@@ -49,6 +49,10 @@ SIGNATURES = {
     "vllm_amd_silu_and_mul_quant": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "vllm_amd_compute_slot_mapping": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "vllm_amd_swap_blocks": [_vp, _vp, _i64, _vp, _i64, _vp],
+    "vllm_amd_context_attention_fwd": [
+        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
+        _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _i,
+        _i, _i, _vp],
     "vllm_amd_set_tuning": [C.c_char_p, _i],
 }
 

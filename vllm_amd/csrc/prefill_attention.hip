@@ -1,0 +1,457 @@
+// Prefill / chunked-prefill attention with a paged prefix: the MFMA-bound
+// sibling of the decode kernel.  Replaces context_attention_fwd
+// (vllm/attention/ops/prefix_prefill.py:726-913; Triton kernels _fwd_kernel :36-288 and
+// _fwd_kernel_alibi :477-722): every query token of a sequence attends to
+//   (1) the sequence's cached context in the PAGED KV cache (no causal mask), then
+//   (2) the new tokens' dense K / V (causal mask),
+// with one online softmax over both.
+//
+// One workgroup (4 waves) per (128 query rows, head, sequence); a wave owns 32 rows = two
+// 16-column tiles of the TRANSPOSED problem, exactly as in the decode kernel:
+//   S^T[n, m] = K[n, :] . Q[m, :]      (A = K rows from LDS, B = Q^T from registers)
+//   O^T[d, m] += V^T[d, n] . P^T[n, m] (A = V^T rows from LDS, B = P^T)
+// The C layout of S^T (lane holds 4 consecutive n of one m) IS the B layout of P^T once
+// the contraction index of the PV product is permuted (slots 0-3 <- tile a, 4-7 <- tile b,
+// the V^T fragment is read with the same permutation): P never leaves the registers.
+// KV tiles of 64 tokens go global -> registers -> LDS (converted on the way: fp8 context is
+// scaled and rounded to the query dtype like the reference, new V is transposed), with the
+// next tile's global loads in flight during the MFMAs.
+#include "mma.cuh"
+
+#include <float.h>
+
+namespace va {
+
+constexpr int PF_BM = 128, PF_BN = 64, PF_THREADS = 256;
+
+struct PrefillParams {
+  void* o; const void* q; const void* k; const void* v;
+  const uint8_t* k_cache; const uint8_t* v_cache;
+  const int* b_loc; const int* b_start_loc; const int* b_seq_len;
+  const float* k_scale; const float* v_scale; const float* alibi_slopes;
+  const float* fp8_out_scale;
+  int num_heads, num_kv_heads;
+  int64_t b_loc_stride, q_stride_t, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h,
+      o_stride_t, o_stride_h, kc_block_bytes, kc_head_bytes, vc_block_bytes, vc_head_bytes;
+  float sm_scale; int sliding_window; int skip_decode;
+};
+
+// two e4m3 bytes (half `hi` of w) * scale -> two packed T
+template <typename T>
+__device__ __forceinline__ uint32_t fp8x2_scaled(uint32_t w, bool hi, float scale) {
+  const f32x2 f = fp8x2_to_f32(w, hi);
+  return Mma<T>::pack2(f[0] * scale, f[1] * scale);
+}
+// 8 e4m3 bytes (two dwords) * scale -> 8 T
+template <typename T>
+__device__ __forceinline__ uint4 fp8x8_scaled(uint32_t w0, uint32_t w1, float scale) {
+  return make_uint4(fp8x2_scaled<T>(w0, false, scale), fp8x2_scaled<T>(w0, true, scale),
+                    fp8x2_scaled<T>(w1, false, scale), fp8x2_scaled<T>(w1, true, scale));
+}
+
+template <typename T, bool FP8, int D, int BS>
+__global__ __launch_bounds__(PF_THREADS, 2) void prefill_kernel(const PrefillParams p) {
+  static_assert(D % 32 == 0 && D <= 128, "");
+  constexpr int KCH = D / 8;                 // 16-byte chunks per K row (8 elements each)
+  constexpr int KROW = D * 2;                // bytes per K row in LDS
+  constexpr int KSWZ = (KCH % 16 == 0) ? 15 : (KCH % 8 == 0) ? 7 : 3;   // chunk ^= tok & KSWZ
+  constexpr int K_BYTES = PF_BN * KROW;
+  constexpr int VROW = PF_BN * 2;            // bytes per V^T row (64 tokens)
+  constexpr int V_BYTES = D * VROW;
+  constexpr int QK_STEPS = D / 32, DT = D / 16;
+  // staging work per thread
+  constexpr int K16_ITEMS = PF_BN * KCH / PF_THREADS;              // 16-bit K: (tok, chunk)
+  constexpr int K8_ITEMS = (PF_BN * (D / 16) + PF_THREADS - 1) / PF_THREADS;   // fp8 K
+  constexpr int V16_ITEMS = D * 8 / PF_THREADS;                     // 16-bit V: (d, 8 tok)
+  constexpr int V8_ITEMS = (D * 4 + PF_THREADS - 1) / PF_THREADS;   // fp8 V: (d, 16 tok)
+  constexpr int NSTG = K16_ITEMS;            // staging registers per operand (>= every count)
+  static_assert(K16_ITEMS >= K8_ITEMS && K16_ITEMS >= V16_ITEMS && K16_ITEMS >= V8_ITEMS, "");
+  __shared__ __attribute__((aligned(16))) uint8_t lds[K_BYTES + V_BYTES];
+  uint8_t* lds_k = lds;
+  uint8_t* lds_v = lds + K_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int start_m = blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
+  const int kvh = head / (p.num_heads / p.num_kv_heads);
+
+  const int seq_len = p.b_seq_len[seq];
+  const int tok0 = p.b_start_loc[seq];
+  const int qlen = p.b_start_loc[seq + 1] - tok0;
+  const int ctx = seq_len - qlen;
+  if (p.skip_decode && qlen == 1) return;
+  if (start_m * PF_BM >= qlen) return;   // the reference computes and stores nothing here
+
+  const bool alibi = p.alibi_slopes != nullptr;
+  const float slope2 = alibi ? p.alibi_slopes[head] * kLog2e : 0.f;
+  const int window = alibi ? 0 : p.sliding_window;   // the alibi kernel has no window
+  const float sc2 = p.sm_scale * kLog2e;
+  float kscale = 1.f, vscale = 1.f;
+  if constexpr (FP8) { kscale = *p.k_scale; vscale = *p.v_scale; }
+
+  // ---- Q^T fragments: column m = c16 of the wave's tile mt, k = d = 32 ks + 8 g4 + j ------
+  const int m_wave = start_m * PF_BM + 32 * wave;
+  uint4 qf[2][QK_STEPS];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = m_wave + 16 * mt + c16;
+    const T* qp = (const T*)p.q + (int64_t)(tok0 + (m < qlen ? m : 0)) * p.q_stride_t +
+                  (int64_t)head * p.q_stride_h;
+#pragma unroll
+    for (int ks = 0; ks < QK_STEPS; ++ks) {
+      const uint4 v = *reinterpret_cast<const uint4*>(qp + 32 * ks + 8 * g4);
+      qf[mt][ks] = m < qlen ? v : make_uint4(0, 0, 0, 0);
+    }
+  }
+
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  f32x4 o[DT][2];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) { o[i][0] = (f32x4){0, 0, 0, 0}; o[i][1] = (f32x4){0, 0, 0, 0}; }
+
+  const int ctx_tiles = (ctx + PF_BN - 1) / PF_BN;
+  const int new_end = min((start_m + 1) * PF_BM, qlen);      // causal bound of this row block
+  const int new_tiles = (new_end + PF_BN - 1) / PF_BN;
+  const int ntiles = ctx_tiles + new_tiles;
+  const int* bl = p.b_loc + (int64_t)seq * p.b_loc_stride;
+
+  uint4 kst[NSTG], vst[NSTG];   // staging registers of the tile being loaded
+
+  // ---- global -> registers --------------------------------------------------------------------
+  auto load_tile = [&](int t) {
+    if (t < ctx_tiles) {
+      const int n0 = t * PF_BN;
+      if constexpr (!FP8) {
+#pragma unroll
+        for (int i = 0; i < K16_ITEMS; ++i) {          // item -> (tok = item & 63, chunk)
+          const int item = tid + PF_THREADS * i;
+          const int tok = item & 63, c = item >> 6;
+          const int n = min(n0 + tok, ctx - 1);
+          const uint8_t* src = p.k_cache + (int64_t)bl[n / BS] * p.kc_block_bytes +
+                               (int64_t)kvh * p.kc_head_bytes + ((c * BS + n % BS) << 4);
+          kst[i] = *reinterpret_cast<const uint4*>(src);
+        }
+#pragma unroll
+        for (int i = 0; i < V16_ITEMS; ++i) {          // item -> (page, d, 8-token chunk of the page)
+          const int item = tid + PF_THREADS * i;
+          constexpr int CPP = BS / 8;
+          const int j = item % CPP, d = (item / CPP) % D, pg = item / (CPP * D);
+          const int n = n0 + pg * BS + 8 * j;
+          const int nc = min(n, ctx - 1);
+          const uint8_t* src = p.v_cache + (int64_t)bl[nc / BS] * p.vc_block_bytes +
+                               (int64_t)kvh * p.vc_head_bytes + ((d * BS + (n % BS)) << 1);
+          // stale cache bytes of tokens >= ctx may be NaN, and 0 * NaN = NaN in the PV product
+          vst[i] = mask_halfs(*reinterpret_cast<const uint4*>(src), ctx - n);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < K8_ITEMS; ++i) {           // item -> (tok, 16-element chunk)
+          const int item = tid + PF_THREADS * i;
+          const int tok = item & 63, cc = min(item >> 6, D / 16 - 1);
+          const int n = min(n0 + tok, ctx - 1);
+          const uint8_t* src = p.k_cache + (int64_t)bl[n / BS] * p.kc_block_bytes +
+                               (int64_t)kvh * p.kc_head_bytes + ((cc * BS + n % BS) << 4);
+          kst[i] = *reinterpret_cast<const uint4*>(src);
+        }
+#pragma unroll
+        for (int i = 0; i < V8_ITEMS; ++i) {           // item -> (page, d, 16-token chunk)
+          const int item = tid + PF_THREADS * i;
+          constexpr int CPP = BS / 16;
+          const int j = item % CPP, d = (item / CPP) % D, pg = min(item / (CPP * D), PF_BN / BS - 1);
+          const int n = n0 + pg * BS + 16 * j;
+          const int nc = min(n, ctx - 1);
+          const uint8_t* src = p.v_cache + (int64_t)bl[nc / BS] * p.vc_block_bytes +
+                               (int64_t)kvh * p.vc_head_bytes + (d * BS + (n % BS));
+          vst[i] = mask_bytes(*reinterpret_cast<const uint4*>(src), ctx - n);
+        }
+      }
+    } else {
+      const int n0 = (t - ctx_tiles) * PF_BN;
+#pragma unroll
+      for (int i = 0; i < K16_ITEMS; ++i) {            // item -> (tok, chunk) for K and for V
+        const int item = tid + PF_THREADS * i;
+        const int tok = item & 63, c = item >> 6;
+        const int n = n0 + tok;
+        const int64_t row = tok0 + min(n, qlen - 1);
+        kst[i] = *reinterpret_cast<const uint4*>((const T*)p.k + row * p.k_stride_t +
+                                                 (int64_t)kvh * p.k_stride_h + 8 * c);
+        const uint4 vv = *reinterpret_cast<const uint4*>((const T*)p.v + row * p.v_stride_t +
+                                                         (int64_t)kvh * p.v_stride_h + 8 * c);
+        vst[i] = n < qlen ? vv : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- registers -> LDS (K tile [tok][D], V^T tile [d][tok], both chunk-swizzled) ----------------
+  auto k_slot = [&](int tok, int c) { return lds_k + tok * KROW + ((c ^ (tok & KSWZ)) << 4); };
+  auto v_slot = [&](int d, int tc) { return lds_v + d * VROW + ((tc ^ ((d >> 1) & 7)) << 4); };
+  auto store_tile = [&](int t) {
+    if (t < ctx_tiles) {
+      if constexpr (!FP8) {
+#pragma unroll
+        for (int i = 0; i < K16_ITEMS; ++i) {
+          const int item = tid + PF_THREADS * i;
+          *reinterpret_cast<uint4*>(k_slot(item & 63, item >> 6)) = kst[i];
+        }
+#pragma unroll
+        for (int i = 0; i < V16_ITEMS; ++i) {
+          const int item = tid + PF_THREADS * i;
+          constexpr int CPP = BS / 8;
+          const int j = item % CPP, d = (item / CPP) % D, pg = item / (CPP * D);
+          *reinterpret_cast<uint4*>(v_slot(d, pg * CPP + j)) = vst[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < K8_ITEMS; ++i) {
+          const int item = tid + PF_THREADS * i;
+          const int tok = item & 63, cc = item >> 6;
+          if (cc < D / 16) {   // k = (fp8 -> f32 * k_scale).to(q dtype)  (prefix_prefill.py:168-169)
+            *reinterpret_cast<uint4*>(k_slot(tok, 2 * cc)) = fp8x8_scaled<T>(kst[i].x, kst[i].y, kscale);
+            *reinterpret_cast<uint4*>(k_slot(tok, 2 * cc + 1)) = fp8x8_scaled<T>(kst[i].z, kst[i].w, kscale);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < V8_ITEMS; ++i) {
+          const int item = tid + PF_THREADS * i;
+          constexpr int CPP = BS / 16;
+          const int j = item % CPP, d = (item / CPP) % D, pg = item / (CPP * D);
+          const int tc = (pg * BS + 16 * j) >> 3;
+          if (item < 4 * D) {   // v = (fp8 -> f32 * v_scale).to(q dtype)  (:212-213)
+            *reinterpret_cast<uint4*>(v_slot(d, tc)) = fp8x8_scaled<T>(vst[i].x, vst[i].y, vscale);
+            *reinterpret_cast<uint4*>(v_slot(d, tc + 1)) = fp8x8_scaled<T>(vst[i].z, vst[i].w, vscale);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < K16_ITEMS; ++i) {
+        const int item = tid + PF_THREADS * i;
+        const int tok = item & 63, c = item >> 6;
+        *reinterpret_cast<uint4*>(k_slot(tok, c)) = kst[i];
+        // V: 8 d of one token -> column `tok` of 8 V^T rows
+        const uint32_t w[4] = {vst[i].x, vst[i].y, vst[i].z, vst[i].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int d = 8 * c + e;
+          *reinterpret_cast<uint16_t*>(v_slot(d, tok >> 3) + (tok & 7) * 2) =
+              (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+        }
+      }
+    }
+  };
+
+  // ---- one KV tile: S^T, online softmax, O^T ------------------------------------------------------
+  auto compute_tile = [&](int t) {
+    const bool is_ctx = t < ctx_tiles;
+    const int n0 = is_ctx ? t * PF_BN : (t - ctx_tiles) * PF_BN;
+    f32x4 s[4][2];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      s[nt][0] = (f32x4){0, 0, 0, 0};
+      s[nt][1] = (f32x4){0, 0, 0, 0};
+      const int tok = 16 * nt + c16;
+#pragma unroll
+      for (int ks = 0; ks < QK_STEPS; ++ks) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(k_slot(tok, 4 * ks + g4));
+        s[nt][0] = Mma<T>::mfma(kf, qf[0][ks], s[nt][0]);
+        s[nt][1] = Mma<T>::mfma(kf, qf[1][ks], s[nt][1]);
+      }
+    }
+    // lane holds S^T[n = n0 + 16 nt + 4 g4 + r][m = m_wave + 16 mt + c16]
+    uint32_t pk[4][2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = m_wave + 16 * mt + c16;      // query index within the new tokens
+      const int qpos = ctx + m;                   // position in the sequence
+      float mx = -INFINITY;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + 16 * nt + 4 * g4 + r;
+          const int kpos = is_ctx ? n : ctx + n;
+          // context: every cached token is visible; new tokens: causal (prefix_prefill.py:175, 249)
+          const bool valid = is_ctx ? n < ctx : n <= m;
+          float x = s[nt][mt][r] * sc2;
+          if (alibi) {   // (:603-608): bias where it is <= 0 and the row is real, else -inf
+            const float bias = (float)(kpos - qpos) * slope2;
+            x = (bias <= 0.f && qpos < seq_len) ? x + bias : -INFINITY;
+          } else if (window > 0 && qpos - kpos >= window) {
+            x = -10000.0f * kLog2e;               // (:190-192, :251-254): not -inf
+          }
+          x = valid ? x : -INFINITY;
+          s[nt][mt][r] = x;
+          mx = fmaxf(mx, x);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[mt], mx);
+      // a column with nothing visible yet keeps m = -inf; avoid (-inf) - (-inf)
+      const float m_use = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = fast_exp2(m_run[mt] - m_use);
+      m_run[mt] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          e[r] = fast_exp2(s[nt][mt][r] - m_use);
+          psum += e[r];
+        }
+        pk[nt][mt][0] = Mma<T>::pack2(e[0], e[1]);   // p.to(v.dtype) (:216)
+        pk[nt][mt][1] = Mma<T>::pack2(e[2], e[3]);
+      }
+      l_run[mt] = l_run[mt] * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt][mt] *= alpha;
+    }
+    // O^T += V^T . P^T, contraction slots: j < 4 -> token 16 ta + 4 g4 + j, j >= 4 -> tile tb
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      const int ta = 2 * ks2, tb = ta + 1;
+      const uint4 pb0 = make_uint4(pk[ta][0][0], pk[ta][0][1], pk[tb][0][0], pk[tb][0][1]);
+      const uint4 pb1 = make_uint4(pk[ta][1][0], pk[ta][1][1], pk[tb][1][0], pk[tb][1][1]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = 16 * dt + c16;
+        const uint2 va = *reinterpret_cast<const uint2*>(v_slot(d, 2 * ta + (g4 >> 1)) + (g4 & 1) * 8);
+        const uint2 vb = *reinterpret_cast<const uint2*>(v_slot(d, 2 * tb + (g4 >> 1)) + (g4 & 1) * 8);
+        const uint4 vf = make_uint4(va.x, va.y, vb.x, vb.y);
+        o[dt][0] = Mma<T>::mfma(vf, pb0, o[dt][0]);
+        o[dt][1] = Mma<T>::mfma(vf, pb1, o[dt][1]);
+      }
+    }
+  };
+
+  // ---- pipeline: the next tile's global loads fly under the MFMAs of the current one ---------------
+  if (ntiles > 0) load_tile(0);
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();          // everyone is done reading the previous tile
+    store_tile(t);
+    __syncthreads();
+    if (t + 1 < ntiles) load_tile(t + 1);
+    compute_tile(t);
+  }
+
+  // ---- O^T / l -> out: lane holds O^T[d = 16 dt + 4 g4 + r][m] ---------------------------------------
+  const bool fp8_out = p.fp8_out_scale != nullptr;
+  const float out_inv = fp8_out ? 1.0f / *p.fp8_out_scale : 1.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    float l = l_run[mt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const int m = m_wave + 16 * mt + c16;
+    if (m >= qlen) continue;
+    const float inv = 1.0f / l;   // acc / l_i (:276)
+    if (!fp8_out) {
+      T* op = (T*)p.o + (int64_t)(tok0 + m) * p.o_stride_t + (int64_t)head * p.o_stride_h;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const uint2 w = make_uint2(Mma<T>::pack2(o[dt][mt][0] * inv, o[dt][mt][1] * inv),
+                                   Mma<T>::pack2(o[dt][mt][2] * inv, o[dt][mt][3] * inv));
+        *reinterpret_cast<uint2*>(op + 16 * dt + 4 * g4) = w;
+      }
+    } else {
+      // acc / out_scale, clamp to the fp8 range, store e4m3 (:282-287)
+      uint8_t* op = (uint8_t*)p.o + (int64_t)(tok0 + m) * p.o_stride_t + (int64_t)head * p.o_stride_h;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          y[r] = fmaxf(-448.0f, fminf(o[dt][mt][r] * inv * out_inv, 448.0f));
+        *reinterpret_cast<uint32_t*>(op + 16 * dt + 4 * g4) = f32x4_to_fp8x4(y[0], y[1], y[2], y[3]);
+      }
+    }
+  }
+}
+
+template <typename T, bool FP8, int D>
+static void launch_bs(const PrefillParams& p, int block_size, dim3 grid, hipStream_t st) {
+  if (block_size == 16)
+    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 16>), grid, dim3(PF_THREADS), 0, st, p);
+  else
+    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 32>), grid, dim3(PF_THREADS), 0, st, p);
+}
+template <typename T, bool FP8>
+static void launch_d(const PrefillParams& p, int head_size, int block_size, dim3 grid, hipStream_t st) {
+  switch (head_size) {
+    case 32: launch_bs<T, FP8, 32>(p, block_size, grid, st); break;
+    case 64: launch_bs<T, FP8, 64>(p, block_size, grid, st); break;
+    case 96: launch_bs<T, FP8, 96>(p, block_size, grid, st); break;
+    default: launch_bs<T, FP8, 128>(p, block_size, grid, st); break;
+  }
+}
+
+}  // namespace va
+
+using namespace va;
+
+extern "C" int vllm_amd_context_attention_fwd(
+    void* o, const void* q, const void* k, const void* v, const void* k_cache, const void* v_cache,
+    const int* b_loc, const int* b_start_loc, const int* b_seq_len, const float* k_scale,
+    const float* v_scale, const float* alibi_slopes, const float* fp8_out_scale, int batch,
+    int num_heads, int num_kv_heads, int head_size, int block_size, int max_input_len,
+    int64_t b_loc_stride, int64_t q_stride_t, int64_t q_stride_h, int64_t k_stride_t,
+    int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, int64_t o_stride_t,
+    int64_t o_stride_h, int64_t kc_block_stride, int64_t kc_head_stride, int64_t vc_block_stride,
+    int64_t vc_head_stride, float sm_scale, int sliding_window, int skip_decode, int dtype,
+    int kv_cache_dtype, void* stream) {
+  const char* op = "context_attention_fwd";
+  VA_REQUIRE(batch >= 0 && max_input_len >= 0, VLLM_AMD_EINVAL, "%s: negative size", op);
+  if (batch == 0 || max_input_len == 0 || num_heads == 0) return VLLM_AMD_OK;
+  VA_REQUIRE(o && q && k && v && k_cache && v_cache && b_loc && b_start_loc && b_seq_len,
+             VLLM_AMD_EINVAL, "%s: null pointer", op);
+  VA_REQUIRE(dtype == VLLM_AMD_F16 || dtype == VLLM_AMD_BF16, VLLM_AMD_EUNSUPPORTED,
+             "%s: query dtype must be float16 or bfloat16", op);
+  VA_REQUIRE(kv_cache_dtype == VLLM_AMD_KV_AUTO || kv_cache_dtype == VLLM_AMD_KV_FP8_E4M3,
+             VLLM_AMD_EUNSUPPORTED, "Unsupported FP8 dtype: %d", kv_cache_dtype);
+  VA_REQUIRE(head_size == 32 || head_size == 64 || head_size == 96 || head_size == 128,
+             VLLM_AMD_EUNSUPPORTED, "%s: unsupported head size: %d (32, 64, 96, 128)", op,
+             head_size);
+  VA_REQUIRE(block_size == 16 || block_size == 32, VLLM_AMD_EUNSUPPORTED,
+             "%s: unsupported block size: %d (16, 32)", op, block_size);
+  VA_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, VLLM_AMD_EINVAL,
+             "%s: num_heads must be a multiple of num_kv_heads", op);
+  VA_REQUIRE(kv_cache_dtype == VLLM_AMD_KV_AUTO || (k_scale && v_scale), VLLM_AMD_EINVAL,
+             "%s: fp8 cache needs k_scale and v_scale", op);
+  VA_REQUIRE(q_stride_t % 8 == 0 && q_stride_h % 8 == 0 && k_stride_t % 8 == 0 &&
+                 k_stride_h % 8 == 0 && v_stride_t % 8 == 0 && v_stride_h % 8 == 0 &&
+                 o_stride_t % 4 == 0 && o_stride_h % 4 == 0 && (((uintptr_t)q) & 15) == 0 &&
+                 (((uintptr_t)k) & 15) == 0 && (((uintptr_t)v) & 15) == 0 &&
+                 (((uintptr_t)o) & 7) == 0 && (((uintptr_t)k_cache) & 15) == 0 &&
+                 (((uintptr_t)v_cache) & 15) == 0,
+             VLLM_AMD_EUNSUPPORTED, "%s: tensors must be 16-byte aligned with strides that are multiples of 8", op);
+  const int es = kv_cache_dtype == VLLM_AMD_KV_AUTO ? 2 : 1;
+  PrefillParams p;
+  p.o = o; p.q = q; p.k = k; p.v = v;
+  p.k_cache = (const uint8_t*)k_cache; p.v_cache = (const uint8_t*)v_cache;
+  p.b_loc = b_loc; p.b_start_loc = b_start_loc; p.b_seq_len = b_seq_len;
+  p.k_scale = k_scale; p.v_scale = v_scale; p.alibi_slopes = alibi_slopes;
+  p.fp8_out_scale = fp8_out_scale;
+  p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
+  p.b_loc_stride = b_loc_stride;
+  p.q_stride_t = q_stride_t; p.q_stride_h = q_stride_h;
+  p.k_stride_t = k_stride_t; p.k_stride_h = k_stride_h;
+  p.v_stride_t = v_stride_t; p.v_stride_h = v_stride_h;
+  p.o_stride_t = o_stride_t; p.o_stride_h = o_stride_h;
+  p.kc_block_bytes = kc_block_stride * es; p.kc_head_bytes = kc_head_stride * es;
+  p.vc_block_bytes = vc_block_stride * es; p.vc_head_bytes = vc_head_stride * es;
+  p.sm_scale = sm_scale;
+  p.sliding_window = sliding_window > 0 ? sliding_window : 0;
+  p.skip_decode = skip_decode;
+  const dim3 grid((max_input_len + PF_BM - 1) / PF_BM, num_heads, batch);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VLLM_AMD_BF16) {
+    if (es == 2) launch_d<bf16_t, false>(p, head_size, block_size, grid, st);
+    else launch_d<bf16_t, true>(p, head_size, block_size, grid, st);
+  } else {
+    if (es == 2) launch_d<f16_t, false>(p, head_size, block_size, grid, st);
+    else launch_d<f16_t, true>(p, head_size, block_size, grid, st);
+  }
+  VA_LAUNCH_CHECK(op);
+  return VLLM_AMD_OK;
+}
