@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""context_attention_fwd timing: python tools/bench_prefill.py [--kv fp8|auto]"""
+import argparse, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from vllm_amd.attention.ops import context_attention_fwd
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--kv", default="fp8")
+ap.add_argument("--iters", type=int, default=10)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+H, KVH, D, BS = 32, 8, 128, 16
+for (B, ql, cl) in ((4, 2048, 0), (4, 2048, 2048), (1, 8192, 0), (16, 512, 3584), (64, 128, 4096)):
+    T = B * ql
+    g = torch.Generator(device=dev).manual_seed(0)
+    q = (torch.rand((T, H, D), device=dev, generator=g) - 0.5).to(torch.bfloat16)
+    k = (torch.rand((T, KVH, D), device=dev, generator=g) - 0.5).to(torch.bfloat16)
+    v = (torch.rand((T, KVH, D), device=dev, generator=g) - 0.5).to(torch.bfloat16)
+    o = torch.empty_like(q)
+    nb_seq = (cl + BS - 1) // BS + 1
+    NB = B * nb_seq
+    fp8 = a.kv == "fp8"
+    x = 16 if fp8 else 8
+    if fp8:
+        kc = torch.randint(0, 120, (NB, KVH, D // x, BS, x), device=dev, dtype=torch.uint8)
+        vc = torch.randint(0, 120, (NB, KVH, D, BS), device=dev, dtype=torch.uint8)
+    else:
+        kc = (torch.rand((NB, KVH, D // x, BS, x), device=dev) - 0.5).to(torch.bfloat16)
+        vc = (torch.rand((NB, KVH, D, BS), device=dev) - 0.5).to(torch.bfloat16)
+    b_loc = torch.randperm(NB, device=dev).to(torch.int32).view(B, nb_seq)
+    start = (torch.arange(B + 1, device=dev) * ql).to(torch.int32)
+    seql = torch.full((B,), ql + cl, dtype=torch.int32, device=dev)
+    one = torch.full((1,), 0.02, device=dev)
+    fn = lambda: context_attention_fwd(q, k, v, o, a.kv, kc, vc, b_loc, start, seql, ql + cl, ql, one, one)
+    t = bench.time_gpu_graph(fn, a.iters)
+    flops = 4.0 * D * H * B * ql * (cl + (ql + 1) / 2)
+    print(f"B={B:3d} q_len={ql:5d} ctx={cl:5d} kv={a.kv}: {t*1e6:9.1f} us  {flops/t/1e12:7.1f} TFLOP/s "
+          f"({100*flops/t/2.5e15:.1f}% of 2.5 PF bf16)", flush=True)

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "../../include/vllm_amd.h"
 
 namespace va {
@@ -90,6 +93,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(<N-1>); indices are constants
+// from the front end on, so register arrays indexed by them are never demoted to scratch
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 }  // namespace va

@@ -19,10 +19,11 @@
 #include "mma.cuh"
 
 #include <float.h>
+#include <type_traits>
 
 namespace va {
 
-constexpr int PF_BM = 128, PF_BN = 64, PF_THREADS = 256;
+constexpr int PF_BM = 128, PF_BN = 64;
 
 struct PrefillParams {
   void* o; const void* q; const void* k; const void* v;
@@ -36,21 +37,19 @@ struct PrefillParams {
   float sm_scale; int sliding_window; int skip_decode;
 };
 
-// two e4m3 bytes (half `hi` of w) * scale -> two packed T
-template <typename T>
-__device__ __forceinline__ uint32_t fp8x2_scaled(uint32_t w, bool hi, float scale) {
-  const f32x2 f = fp8x2_to_f32(w, hi);
-  return Mma<T>::pack2(f[0] * scale, f[1] * scale);
-}
-// 8 e4m3 bytes (two dwords) * scale -> 8 T
-template <typename T>
-__device__ __forceinline__ uint4 fp8x8_scaled(uint32_t w0, uint32_t w1, float scale) {
-  return make_uint4(fp8x2_scaled<T>(w0, false, scale), fp8x2_scaled<T>(w0, true, scale),
-                    fp8x2_scaled<T>(w1, false, scale), fp8x2_scaled<T>(w1, true, scale));
+// transposing 8-byte LDS read (4 x 16 bit), see compute_tile
+__device__ __forceinline__ uint2 lds_read_tr16(const uint8_t* p) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(uint2, v);
 }
 
-template <typename T, bool FP8, int D, int BS>
-__global__ __launch_bounds__(PF_THREADS, 2) void prefill_kernel(const PrefillParams p) {
+// MT = 16-row query tiles per wave: 2 -> 4 waves of 32 rows (each K / V fragment feeds two
+// MFMAs), 1 -> 8 waves of 16 rows (half the registers per wave: no spills at head size 128).
+template <typename T, bool FP8, int D, int BS, int MT>
+__global__ __launch_bounds__(64 * (PF_BM / (16 * MT)), 2) void prefill_kernel(const PrefillParams p) {
+  constexpr int PF_THREADS = 64 * (PF_BM / (16 * MT));
   static_assert(D % 32 == 0 && D <= 128, "");
   constexpr int KCH = D / 8;                 // 16-byte chunks per K row (8 elements each)
   constexpr int KROW = D * 2;                // bytes per K row in LDS
@@ -60,9 +59,10 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_kernel(const PrefillPar
   constexpr int V_BYTES = D * VROW;
   constexpr int QK_STEPS = D / 32, DT = D / 16;
   // staging work per thread
-  constexpr int K16_ITEMS = PF_BN * KCH / PF_THREADS;              // 16-bit K: (tok, chunk)
+  constexpr int K16_TOTAL = PF_BN * KCH, K8_TOTAL = PF_BN * (D / 16), V16_TOTAL = D * 8, V8_TOTAL = D * 4;
+  constexpr int K16_ITEMS = (K16_TOTAL + PF_THREADS - 1) / PF_THREADS;   // 16-bit K: (tok, chunk)
   constexpr int K8_ITEMS = (PF_BN * (D / 16) + PF_THREADS - 1) / PF_THREADS;   // fp8 K
-  constexpr int V16_ITEMS = D * 8 / PF_THREADS;                     // 16-bit V: (d, 8 tok)
+  constexpr int V16_ITEMS = (V16_TOTAL + PF_THREADS - 1) / PF_THREADS;   // 16-bit V: (d, 8 tok)
   constexpr int V8_ITEMS = (D * 4 + PF_THREADS - 1) / PF_THREADS;   // fp8 V: (d, 16 tok)
   constexpr int NSTG = K16_ITEMS;            // staging registers per operand (>= every count)
   static_assert(K16_ITEMS >= K8_ITEMS && K16_ITEMS >= V16_ITEMS && K16_ITEMS >= V8_ITEMS, "");
@@ -73,7 +73,8 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_kernel(const PrefillPar
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, g4 = lane >> 4;
-  const int start_m = blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
+  // causal: row blocks further down have more KV tiles -> launch them first
+  const int start_m = gridDim.x - 1 - blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
   const int kvh = head / (p.num_heads / p.num_kv_heads);
 
   const int seq_len = p.b_seq_len[seq];
@@ -91,10 +92,10 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_kernel(const PrefillPar
   if constexpr (FP8) { kscale = *p.k_scale; vscale = *p.v_scale; }
 
   // ---- Q^T fragments: column m = c16 of the wave's tile mt, k = d = 32 ks + 8 g4 + j ------
-  const int m_wave = start_m * PF_BM + 32 * wave;
-  uint4 qf[2][QK_STEPS];
+  const int m_wave = start_m * PF_BM + 16 * MT * wave;
+  uint4 qf[MT][QK_STEPS];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int m = m_wave + 16 * mt + c16;
     const T* qp = (const T*)p.q + (int64_t)(tok0 + (m < qlen ? m : 0)) * p.q_stride_t +
                   (int64_t)head * p.q_stride_h;
@@ -105,10 +106,15 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_kernel(const PrefillPar
     }
   }
 
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-  f32x4 o[DT][2];
+  float m_run[MT], l_run[MT];
+  f32x4 o[DT][MT];
 #pragma unroll
-  for (int i = 0; i < DT; ++i) { o[i][0] = (f32x4){0, 0, 0, 0}; o[i][1] = (f32x4){0, 0, 0, 0}; }
+  for (int mt = 0; mt < MT; ++mt) {
+    m_run[mt] = -INFINITY;
+    l_run[mt] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i][mt] = (f32x4){0, 0, 0, 0};
+  }
 
   const int ctx_tiles = (ctx + PF_BN - 1) / PF_BN;
   const int new_end = min((start_m + 1) * PF_BM, qlen);      // causal bound of this row block
@@ -116,174 +122,219 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_kernel(const PrefillPar
   const int ntiles = ctx_tiles + new_tiles;
   const int* bl = p.b_loc + (int64_t)seq * p.b_loc_stride;
 
-  uint4 kst[NSTG], vst[NSTG];   // staging registers of the tile being loaded
+  // staging registers of the tile being loaded (native vectors: HIP's uint4 struct arrays were
+  // demoted to scratch memory by the compiler, with a wait on every load right behind it)
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  u32x4 kst[NSTG], vst[NSTG];
+  auto as_u4 = [](u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); };
 
-  // ---- global -> registers --------------------------------------------------------------------
-  auto load_tile = [&](int t) {
+  // Physical block numbers a thread needs for a context tile.  Which page of the tile an item
+  // reads is fixed per thread (K: every item of a thread is the same token; V: one page per
+  // item), so each thread fetches exactly those block-table entries -- ONE TILE EARLIER than
+  // the K/V loads that use them, so no load of the steady state waits on a dependent
+  // block-table read.  Pages past the context are clamped to its last page (masked tokens).
+  constexpr int PPT = PF_BN / BS;   // pages per tile
+  constexpr int VPG = FP8 ? V8_ITEMS : V16_ITEMS;
+  struct Pages { int k; int v[VPG]; };
+  const int last_page = ctx > 0 ? (ctx - 1) / BS : 0;
+  auto v_page_of_item = [&](int i) {   // page (within the tile) of V item i of this thread
+    constexpr int CPP = FP8 ? BS / 16 : BS / 8;
+    return min((tid + PF_THREADS * i) / (CPP * D), PPT - 1);
+  };
+  auto load_pages = [&](int t) {
+    Pages pg;
+    const bool on = t < ctx_tiles;
+    pg.k = on ? bl[min(t * PPT + (tid & 63) / BS, last_page)] : 0;
+    static_for<VPG>([&](auto ic_) {
+      constexpr int i = decltype(ic_)::value;
+      pg.v[i] = on ? bl[min(t * PPT + v_page_of_item(i), last_page)] : 0;
+    });
+    return pg;
+  };
+
+  // ---- global -> registers: raw loads only (masks and conversions happen in store_tile, so
+  // nothing here waits for the data) ---------------------------------------------------------
+  auto load_tile = [&](int t, const Pages& pg) {
     if (t < ctx_tiles) {
-      const int n0 = t * PF_BN;
       if constexpr (!FP8) {
-#pragma unroll
-        for (int i = 0; i < K16_ITEMS; ++i) {          // item -> (tok = item & 63, chunk)
-          const int item = tid + PF_THREADS * i;
+        static_for<K16_ITEMS>([&](auto ic_) {
+          constexpr int i = decltype(ic_)::value;          // item -> (tok = item & 63, chunk)
+          const int item = min(tid + PF_THREADS * i, K16_TOTAL - 1);
           const int tok = item & 63, c = item >> 6;
-          const int n = min(n0 + tok, ctx - 1);
-          const uint8_t* src = p.k_cache + (int64_t)bl[n / BS] * p.kc_block_bytes +
-                               (int64_t)kvh * p.kc_head_bytes + ((c * BS + n % BS) << 4);
-          kst[i] = *reinterpret_cast<const uint4*>(src);
-        }
-#pragma unroll
-        for (int i = 0; i < V16_ITEMS; ++i) {          // item -> (page, d, 8-token chunk of the page)
-          const int item = tid + PF_THREADS * i;
+          const uint8_t* src = p.k_cache + (int64_t)pg.k * p.kc_block_bytes +
+                               (int64_t)kvh * p.kc_head_bytes + ((c * BS + tok % BS) << 4);
+          kst[i] = *reinterpret_cast<const u32x4*>(src);
+        });
+        static_for<V16_ITEMS>([&](auto ic_) {
+          constexpr int i = decltype(ic_)::value;          // item -> (page, d, 8-token chunk of the page)
+          const int item = min(tid + PF_THREADS * i, V16_TOTAL - 1);
           constexpr int CPP = BS / 8;
-          const int j = item % CPP, d = (item / CPP) % D, pg = item / (CPP * D);
-          const int n = n0 + pg * BS + 8 * j;
-          const int nc = min(n, ctx - 1);
-          const uint8_t* src = p.v_cache + (int64_t)bl[nc / BS] * p.vc_block_bytes +
-                               (int64_t)kvh * p.vc_head_bytes + ((d * BS + (n % BS)) << 1);
-          // stale cache bytes of tokens >= ctx may be NaN, and 0 * NaN = NaN in the PV product
-          vst[i] = mask_halfs(*reinterpret_cast<const uint4*>(src), ctx - n);
-        }
+          const int j = item % CPP, d = (item / CPP) % D;
+          const uint8_t* src = p.v_cache + (int64_t)pg.v[i] * p.vc_block_bytes +
+                               (int64_t)kvh * p.vc_head_bytes + ((d * BS + 8 * j) << 1);
+          vst[i] = *reinterpret_cast<const u32x4*>(src);
+        });
       } else {
-#pragma unroll
-        for (int i = 0; i < K8_ITEMS; ++i) {           // item -> (tok, 16-element chunk)
+        static_for<K8_ITEMS>([&](auto ic_) {
+          constexpr int i = decltype(ic_)::value;           // item -> (tok, 16-element chunk)
           const int item = tid + PF_THREADS * i;
           const int tok = item & 63, cc = min(item >> 6, D / 16 - 1);
-          const int n = min(n0 + tok, ctx - 1);
-          const uint8_t* src = p.k_cache + (int64_t)bl[n / BS] * p.kc_block_bytes +
-                               (int64_t)kvh * p.kc_head_bytes + ((cc * BS + n % BS) << 4);
-          kst[i] = *reinterpret_cast<const uint4*>(src);
-        }
-#pragma unroll
-        for (int i = 0; i < V8_ITEMS; ++i) {           // item -> (page, d, 16-token chunk)
+          const uint8_t* src = p.k_cache + (int64_t)pg.k * p.kc_block_bytes +
+                               (int64_t)kvh * p.kc_head_bytes + ((cc * BS + tok % BS) << 4);
+          kst[i] = *reinterpret_cast<const u32x4*>(src);
+        });
+        static_for<V8_ITEMS>([&](auto ic_) {
+          constexpr int i = decltype(ic_)::value;           // item -> (page, d, 16-token chunk)
           const int item = tid + PF_THREADS * i;
           constexpr int CPP = BS / 16;
-          const int j = item % CPP, d = (item / CPP) % D, pg = min(item / (CPP * D), PF_BN / BS - 1);
-          const int n = n0 + pg * BS + 16 * j;
-          const int nc = min(n, ctx - 1);
-          const uint8_t* src = p.v_cache + (int64_t)bl[nc / BS] * p.vc_block_bytes +
-                               (int64_t)kvh * p.vc_head_bytes + (d * BS + (n % BS));
-          vst[i] = mask_bytes(*reinterpret_cast<const uint4*>(src), ctx - n);
-        }
+          const int j = item % CPP, d = (item / CPP) % D;
+          const uint8_t* src = p.v_cache + (int64_t)pg.v[i] * p.vc_block_bytes +
+                               (int64_t)kvh * p.vc_head_bytes + (d * BS + 16 * j);
+          vst[i] = *reinterpret_cast<const u32x4*>(src);
+        });
       }
     } else {
       const int n0 = (t - ctx_tiles) * PF_BN;
-#pragma unroll
-      for (int i = 0; i < K16_ITEMS; ++i) {            // item -> (tok, chunk) for K and for V
-        const int item = tid + PF_THREADS * i;
+      static_for<K16_ITEMS>([&](auto ic_) {
+        constexpr int i = decltype(ic_)::value;            // item -> (tok, chunk) for K and for V
+        const int item = min(tid + PF_THREADS * i, K16_TOTAL - 1);
         const int tok = item & 63, c = item >> 6;
-        const int n = n0 + tok;
-        const int64_t row = tok0 + min(n, qlen - 1);
-        kst[i] = *reinterpret_cast<const uint4*>((const T*)p.k + row * p.k_stride_t +
+        const int64_t row = tok0 + min(n0 + tok, qlen - 1);
+        kst[i] = *reinterpret_cast<const u32x4*>((const T*)p.k + row * p.k_stride_t +
                                                  (int64_t)kvh * p.k_stride_h + 8 * c);
-        const uint4 vv = *reinterpret_cast<const uint4*>((const T*)p.v + row * p.v_stride_t +
-                                                         (int64_t)kvh * p.v_stride_h + 8 * c);
-        vst[i] = n < qlen ? vv : make_uint4(0, 0, 0, 0);
-      }
+        vst[i] = *reinterpret_cast<const u32x4*>((const T*)p.v + row * p.v_stride_t +
+                                                 (int64_t)kvh * p.v_stride_h + 8 * c);
+      });
     }
   };
 
   // ---- registers -> LDS (K tile [tok][D], V^T tile [d][tok], both chunk-swizzled) ----------------
   auto k_slot = [&](int tok, int c) { return lds_k + tok * KROW + ((c ^ (tok & KSWZ)) << 4); };
   auto v_slot = [&](int d, int tc) { return lds_v + d * VROW + ((tc ^ ((d >> 1) & 7)) << 4); };
+  // new tokens' V stays row-major [tok][D] (a plain copy like K) and is consumed with the
+  // transposing LDS read; chunk pairs (one 16-wide d tile) are swizzled by the token
+  constexpr int VNSWZ = (KCH % 16 == 0) ? 7 : (KCH % 8 == 0) ? 3 : 1;   // stays inside the row
+  auto vn_slot = [&](int tok, int c) { return lds_v + tok * KROW + ((c ^ (2 * (tok & VNSWZ))) << 4); };
   auto store_tile = [&](int t) {
     if (t < ctx_tiles) {
       if constexpr (!FP8) {
-#pragma unroll
-        for (int i = 0; i < K16_ITEMS; ++i) {
+        static_for<K16_ITEMS>([&](auto ic_) {
+          constexpr int i = decltype(ic_)::value;
           const int item = tid + PF_THREADS * i;
-          *reinterpret_cast<uint4*>(k_slot(item & 63, item >> 6)) = kst[i];
-        }
-#pragma unroll
-        for (int i = 0; i < V16_ITEMS; ++i) {
+          if (item < K16_TOTAL) *reinterpret_cast<u32x4*>(k_slot(item & 63, item >> 6)) = kst[i];
+        });
+        static_for<V16_ITEMS>([&](auto ic_) {
+          constexpr int i = decltype(ic_)::value;
           const int item = tid + PF_THREADS * i;
           constexpr int CPP = BS / 8;
           const int j = item % CPP, d = (item / CPP) % D, pg = item / (CPP * D);
-          *reinterpret_cast<uint4*>(v_slot(d, pg * CPP + j)) = vst[i];
-        }
+          // stale cache bytes of tokens >= ctx may be NaN, and 0 * NaN = NaN in the PV product
+          const int n = t * PF_BN + pg * BS + 8 * j;
+          if (item < V16_TOTAL) *reinterpret_cast<uint4*>(v_slot(d, pg * CPP + j)) = mask_halfs(as_u4(vst[i]), ctx - n);
+        });
       } else {
-#pragma unroll
-        for (int i = 0; i < K8_ITEMS; ++i) {
+        static_for<K8_ITEMS>([&](auto ic_) {
+          constexpr int i = decltype(ic_)::value;
           const int item = tid + PF_THREADS * i;
           const int tok = item & 63, cc = item >> 6;
-          if (cc < D / 16) {   // k = (fp8 -> f32 * k_scale).to(q dtype)  (prefix_prefill.py:168-169)
-            *reinterpret_cast<uint4*>(k_slot(tok, 2 * cc)) = fp8x8_scaled<T>(kst[i].x, kst[i].y, kscale);
-            *reinterpret_cast<uint4*>(k_slot(tok, 2 * cc + 1)) = fp8x8_scaled<T>(kst[i].z, kst[i].w, kscale);
+          if (cc < D / 16) {
+            uint4 lo, hi;   // exact widening; k_scale is applied to the scores
+            widen16<T>(as_u4(kst[i]), lo, hi);
+            *reinterpret_cast<uint4*>(k_slot(tok, 2 * cc)) = lo;
+            *reinterpret_cast<uint4*>(k_slot(tok, 2 * cc + 1)) = hi;
           }
-        }
-#pragma unroll
-        for (int i = 0; i < V8_ITEMS; ++i) {
+        });
+        static_for<V8_ITEMS>([&](auto ic_) {
+          constexpr int i = decltype(ic_)::value;
           const int item = tid + PF_THREADS * i;
           constexpr int CPP = BS / 16;
           const int j = item % CPP, d = (item / CPP) % D, pg = item / (CPP * D);
           const int tc = (pg * BS + 16 * j) >> 3;
-          if (item < 4 * D) {   // v = (fp8 -> f32 * v_scale).to(q dtype)  (:212-213)
-            *reinterpret_cast<uint4*>(v_slot(d, tc)) = fp8x8_scaled<T>(vst[i].x, vst[i].y, vscale);
-            *reinterpret_cast<uint4*>(v_slot(d, tc + 1)) = fp8x8_scaled<T>(vst[i].z, vst[i].w, vscale);
+          if (item < 4 * D) {
+            const uint4 raw = mask_bytes(as_u4(vst[i]), ctx - (t * PF_BN + pg * BS + 16 * j));
+            uint4 lo, hi;   // exact widening; v_scale is applied to the probabilities
+            widen16<T>(raw, lo, hi);
+            *reinterpret_cast<uint4*>(v_slot(d, tc)) = lo;
+            *reinterpret_cast<uint4*>(v_slot(d, tc + 1)) = hi;
           }
-        }
+        });
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < K16_ITEMS; ++i) {
+      static_for<K16_ITEMS>([&](auto ic_) {
+        constexpr int i = decltype(ic_)::value;
         const int item = tid + PF_THREADS * i;
         const int tok = item & 63, c = item >> 6;
-        *reinterpret_cast<uint4*>(k_slot(tok, c)) = kst[i];
-        // V: 8 d of one token -> column `tok` of 8 V^T rows
-        const uint32_t w[4] = {vst[i].x, vst[i].y, vst[i].z, vst[i].w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int d = 8 * c + e;
-          *reinterpret_cast<uint16_t*>(v_slot(d, tok >> 3) + (tok & 7) * 2) =
-              (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+        if (item < K16_TOTAL) {
+          *reinterpret_cast<u32x4*>(k_slot(tok, c)) = kst[i];
+          *reinterpret_cast<u32x4*>(vn_slot(tok, c)) =
+              (t - ctx_tiles) * PF_BN + tok < qlen ? vst[i] : (u32x4){0, 0, 0, 0};
         }
-      }
+      });
     }
   };
 
   // ---- one KV tile: S^T, online softmax, O^T ------------------------------------------------------
-  auto compute_tile = [&](int t) {
+  // MASKED = false is the interior fast path (every key of the tile visible to every row of the
+  // wave, no ALiBi / window): 5 VALU per score instead of ~14 -- the softmax, not the MFMA,
+  // is what bounds this kernel (rocprof: 460 VALU per 32 MFMA before the split).
+  // fp8 context: K / V are widened EXACTLY (e4m3 is a subset of f16 / bf16) and k_scale is
+  // folded into the score scale, v_scale into the probabilities -- one rounding less than the
+  // reference's (fp8 * scale).to(dtype), inside the stated tolerance.
+  auto compute_tile = [&](int t, auto masked_c) {
+    constexpr bool MASKED = decltype(masked_c)::value;
     const bool is_ctx = t < ctx_tiles;
     const int n0 = is_ctx ? t * PF_BN : (t - ctx_tiles) * PF_BN;
-    f32x4 s[4][2];
+    const float sct = (FP8 && is_ctx) ? sc2 * kscale : sc2;        // score scale of this tile
+    const float pv = (FP8 && is_ctx) ? vscale : 1.f;                // value scale of this tile
+    f32x4 s[4][MT];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      s[nt][0] = (f32x4){0, 0, 0, 0};
-      s[nt][1] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) s[nt][mt] = (f32x4){0, 0, 0, 0};
       const int tok = 16 * nt + c16;
 #pragma unroll
       for (int ks = 0; ks < QK_STEPS; ++ks) {
         const uint4 kf = *reinterpret_cast<const uint4*>(k_slot(tok, 4 * ks + g4));
-        s[nt][0] = Mma<T>::mfma(kf, qf[0][ks], s[nt][0]);
-        s[nt][1] = Mma<T>::mfma(kf, qf[1][ks], s[nt][1]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) s[nt][mt] = Mma<T>::mfma(kf, qf[mt][ks], s[nt][mt]);
       }
     }
     // lane holds S^T[n = n0 + 16 nt + 4 g4 + r][m = m_wave + 16 mt + c16]
-    uint32_t pk[4][2][2];
+    uint32_t pk[4][MT][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int m = m_wave + 16 * mt + c16;      // query index within the new tokens
-      const int qpos = ctx + m;                   // position in the sequence
+    for (int mt = 0; mt < MT; ++mt) {
       float mx = -INFINITY;
+      if constexpr (MASKED) {
+        const int m = m_wave + 16 * mt + c16;      // query index within the new tokens
+        const int qpos = ctx + m;                   // position in the sequence
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = n0 + 16 * nt + 4 * g4 + r;
-          const int kpos = is_ctx ? n : ctx + n;
-          // context: every cached token is visible; new tokens: causal (prefix_prefill.py:175, 249)
-          const bool valid = is_ctx ? n < ctx : n <= m;
-          float x = s[nt][mt][r] * sc2;
-          if (alibi) {   // (:603-608): bias where it is <= 0 and the row is real, else -inf
-            const float bias = (float)(kpos - qpos) * slope2;
-            x = (bias <= 0.f && qpos < seq_len) ? x + bias : -INFINITY;
-          } else if (window > 0 && qpos - kpos >= window) {
-            x = -10000.0f * kLog2e;               // (:190-192, :251-254): not -inf
+          for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 16 * nt + 4 * g4 + r;
+            const int kpos = is_ctx ? n : ctx + n;
+            // context: every cached token is visible; new tokens: causal (prefix_prefill.py:175, 249)
+            const bool valid = is_ctx ? n < ctx : n <= m;
+            float x = s[nt][mt][r] * sct;
+            if (alibi) {   // (:603-608): bias where it is <= 0 and the row is real, else -inf
+              const float bias = (float)(kpos - qpos) * slope2;
+              x = (bias <= 0.f && qpos < seq_len) ? x + bias : -INFINITY;
+            } else if (window > 0 && qpos - kpos >= window) {
+              x = -10000.0f * kLog2e;               // (:190-192, :251-254): not -inf
+            }
+            x = valid ? x : -INFINITY;
+            s[nt][mt][r] = x;
+            mx = fmaxf(mx, x);
           }
-          x = valid ? x : -INFINITY;
-          s[nt][mt][r] = x;
-          mx = fmaxf(mx, x);
-        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s[nt][mt][r] *= sct;
+            mx = fmaxf(mx, s[nt][mt][r]);
+          }
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[mt], mx);
@@ -299,47 +350,91 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_kernel(const PrefillPar
         for (int r = 0; r < 4; ++r) {
           e[r] = fast_exp2(s[nt][mt][r] - m_use);
           psum += e[r];
+          if constexpr (FP8) e[r] *= pv;
         }
         pk[nt][mt][0] = Mma<T>::pack2(e[0], e[1]);   // p.to(v.dtype) (:216)
         pk[nt][mt][1] = Mma<T>::pack2(e[2], e[3]);
       }
       l_run[mt] = l_run[mt] * alpha + psum;
+      if (__any(alpha != 1.0f)) {
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[dt][mt] *= alpha;
+        for (int dt = 0; dt < DT; ++dt) o[dt][mt] *= alpha;
+      }
     }
     // O^T += V^T . P^T, contraction slots: j < 4 -> token 16 ta + 4 g4 + j, j >= 4 -> tile tb
 #pragma unroll
     for (int ks2 = 0; ks2 < 2; ++ks2) {
       const int ta = 2 * ks2, tb = ta + 1;
-      const uint4 pb0 = make_uint4(pk[ta][0][0], pk[ta][0][1], pk[tb][0][0], pk[tb][0][1]);
-      const uint4 pb1 = make_uint4(pk[ta][1][0], pk[ta][1][1], pk[tb][1][0], pk[tb][1][1]);
+      uint4 pb[MT];
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const int d = 16 * dt + c16;
-        const uint2 va = *reinterpret_cast<const uint2*>(v_slot(d, 2 * ta + (g4 >> 1)) + (g4 & 1) * 8);
-        const uint2 vb = *reinterpret_cast<const uint2*>(v_slot(d, 2 * tb + (g4 >> 1)) + (g4 & 1) * 8);
-        const uint4 vf = make_uint4(va.x, va.y, vb.x, vb.y);
-        o[dt][0] = Mma<T>::mfma(vf, pb0, o[dt][0]);
-        o[dt][1] = Mma<T>::mfma(vf, pb1, o[dt][1]);
+      for (int mt = 0; mt < MT; ++mt)
+        pb[mt] = make_uint4(pk[ta][mt][0], pk[ta][mt][1], pk[tb][mt][0], pk[tb][mt][1]);
+      if (is_ctx) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d = 16 * dt + c16;
+          const uint2 va = *reinterpret_cast<const uint2*>(v_slot(d, 2 * ta + (g4 >> 1)) + (g4 & 1) * 8);
+          const uint2 vb = *reinterpret_cast<const uint2*>(v_slot(d, 2 * tb + (g4 >> 1)) + (g4 & 1) * 8);
+          const uint4 vf = make_uint4(va.x, va.y, vb.x, vb.y);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) o[dt][mt] = Mma<T>::mfma(vf, pb[mt], o[dt][mt]);
+        }
+      } else {
+        // ds_read_b64_tr_b16: the 16 lanes of group g4 read the block of tokens
+        // 16 t + 4 g4 + (0..3) x d 16 dt + (0..15); lane 4q+p addresses token q, d 4p..4p+3 and
+        // lane c16 receives d = 16 dt + c16 of the four tokens: the V^T fragment, transposed
+        // by the hardware.  All 64 lanes are active here (the instruction requires it).
+        const int tq = 4 * g4 + (c16 >> 2);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const uint8_t* va_p = vn_slot(16 * ta + tq, 2 * dt + ((c16 >> 1) & 1)) + (c16 & 1) * 8;
+          const uint8_t* vb_p = vn_slot(16 * tb + tq, 2 * dt + ((c16 >> 1) & 1)) + (c16 & 1) * 8;
+          const uint2 va = lds_read_tr16(va_p), vb = lds_read_tr16(vb_p);
+          const uint4 vf = make_uint4(va.x, va.y, vb.x, vb.y);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) o[dt][mt] = Mma<T>::mfma(vf, pb[mt], o[dt][mt]);
+        }
       }
     }
   };
+  // which path a tile takes for THIS wave (wave-uniform): 0 = skip (new tokens entirely above
+  // the wave's rows), 1 = interior, 2 = masked
+  const int m_hi = m_wave + 16 * MT - 1;       // last query row of the wave
+  auto tile_kind = [&](int t) {
+    if (alibi) return 2;
+    if (t < ctx_tiles) {
+      const int n0 = t * PF_BN;
+      if (n0 + PF_BN > ctx) return 2;
+      return (window > 0 && ctx + m_hi - n0 >= window) ? 2 : 1;
+    }
+    const int n0 = (t - ctx_tiles) * PF_BN;
+    if (n0 > m_hi) return 0;
+    if (n0 + PF_BN - 1 > m_wave) return 2;
+    return (window > 0 && m_hi - n0 >= window) ? 2 : 1;
+  };
 
   // ---- pipeline: the next tile's global loads fly under the MFMAs of the current one ---------------
-  if (ntiles > 0) load_tile(0);
+  Pages pages = load_pages(0);
+  if (ntiles > 0) load_tile(0, pages);
+  pages = load_pages(1);
   for (int t = 0; t < ntiles; ++t) {
     __syncthreads();          // everyone is done reading the previous tile
     store_tile(t);
     __syncthreads();
-    if (t + 1 < ntiles) load_tile(t + 1);
-    compute_tile(t);
+    if (t + 1 < ntiles) {
+      load_tile(t + 1, pages);
+      pages = load_pages(t + 2);
+    }
+    const int kind = tile_kind(t);
+    if (kind == 1) compute_tile(t, std::false_type{});
+    else if (kind == 2) compute_tile(t, std::true_type{});
   }
 
   // ---- O^T / l -> out: lane holds O^T[d = 16 dt + 4 g4 + r][m] ---------------------------------------
   const bool fp8_out = p.fp8_out_scale != nullptr;
   const float out_inv = fp8_out ? 1.0f / *p.fp8_out_scale : 1.f;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     float l = l_run[mt];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -371,10 +466,13 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_kernel(const PrefillPar
 
 template <typename T, bool FP8, int D>
 static void launch_bs(const PrefillParams& p, int block_size, dim3 grid, hipStream_t st) {
+  // head sizes >= 96 do not fit two query tiles per wave in 256 VGPRs without spilling
+  constexpr int MT = D >= 96 ? 1 : 2;
+  constexpr int THREADS = 64 * (PF_BM / (16 * MT));
   if (block_size == 16)
-    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 16>), grid, dim3(PF_THREADS), 0, st, p);
+    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 16, MT>), grid, dim3(THREADS), 0, st, p);
   else
-    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 32>), grid, dim3(PF_THREADS), 0, st, p);
+    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 32, MT>), grid, dim3(THREADS), 0, st, p);
 }
 template <typename T, bool FP8>
 static void launch_d(const PrefillParams& p, int head_size, int block_size, dim3 grid, hipStream_t st) {

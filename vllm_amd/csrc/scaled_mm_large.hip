@@ -29,8 +29,6 @@
 //     instruction writes whole rows of the tile: direct stores from the MFMA layout write
 //     32-byte pieces of 16 rows per instruction and cost 25 us on a 32 MB output.
 #include "common.cuh"
-#include <type_traits>
-#include <utility>
 
 namespace va {
 
@@ -84,15 +82,6 @@ template <int LATER>
 __device__ __forceinline__ void wait_wa(i32x4& w0, i32x4& w1, i32x4& a0, i32x4& a1) {
   static_assert(LATER <= 15, "lgkmcnt is 4 bits");
   asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(w0), "+v"(w1), "+v"(a0), "+v"(a1) : [n] "n"(LATER));
-}
-
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 __device__ __forceinline__ i32x8 cat8(i32x4 lo, i32x4 hi) {
