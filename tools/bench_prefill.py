@@ -9,8 +9,12 @@ from vllm_amd.attention.ops import context_attention_fwd
 ap = argparse.ArgumentParser()
 ap.add_argument("--kv", default="fp8")
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--rows", type=int, default=0, help="query rows per workgroup (tuning pf_rows)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
+if a.rows:
+    from vllm_amd import _lib
+    _lib.set_tuning("pf_rows", a.rows)
 H, KVH, D, BS = 32, 8, 128, 16
 for (B, ql, cl) in ((4, 2048, 0), (4, 2048, 2048), (1, 8192, 0), (16, 512, 3584), (64, 128, 4096)):
     T = B * ql

@@ -23,7 +23,8 @@
 
 namespace va {
 
-constexpr int PF_BM = 128, PF_BN = 64;
+constexpr int PF_BN = 64;
+int g_pf_rows = 0;   // tuning "pf_rows": query rows per workgroup (0 = default)
 
 struct PrefillParams {
   void* o; const void* q; const void* k; const void* v;
@@ -47,9 +48,10 @@ __device__ __forceinline__ uint2 lds_read_tr16(const uint8_t* p) {
 
 // MT = 16-row query tiles per wave: 2 -> 4 waves of 32 rows (each K / V fragment feeds two
 // MFMAs), 1 -> 8 waves of 16 rows (half the registers per wave: no spills at head size 128).
-template <typename T, bool FP8, int D, int BS, int MT>
-__global__ __launch_bounds__(64 * (PF_BM / (16 * MT)), 2) void prefill_kernel(const PrefillParams p) {
-  constexpr int PF_THREADS = 64 * (PF_BM / (16 * MT));
+// NW = waves per workgroup: the workgroup owns PF_BM = 16 MT NW query rows.
+template <typename T, bool FP8, int D, int BS, int MT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams p) {
+  constexpr int PF_THREADS = 64 * NW, PF_BM = 16 * MT * NW;
   static_assert(D % 32 == 0 && D <= 128, "");
   constexpr int KCH = D / 8;                 // 16-byte chunks per K row (8 elements each)
   constexpr int KROW = D * 2;                // bytes per K row in LDS
@@ -273,6 +275,20 @@ __global__ __launch_bounds__(64 * (PF_BM / (16 * MT)), 2) void prefill_kernel(co
     }
   };
 
+  // fragment read addresses, constant over the tiles (the swizzles depend on lane bits only;
+  // the tile-row part is an immediate offset): K per k-step, V^T per 16-token tile, new V per
+  // d tile -- otherwise ~150 VALU of address arithmetic per tile and wave
+  const uint8_t* k_frag[QK_STEPS];
+#pragma unroll
+  for (int ks = 0; ks < QK_STEPS; ++ks) k_frag[ks] = k_slot(c16, 4 * ks + g4);
+  const uint8_t* v_frag[4];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) v_frag[tt] = v_slot(c16, 2 * tt + (g4 >> 1)) + (g4 & 1) * 8;
+  const uint8_t* vn_frag[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+    vn_frag[dt] = vn_slot(4 * g4 + (c16 >> 2), 2 * dt + ((c16 >> 1) & 1)) + (c16 & 1) * 8;
+
   // ---- one KV tile: S^T, online softmax, O^T ------------------------------------------------------
   // MASKED = false is the interior fast path (every key of the tile visible to every row of the
   // wave, no ALiBi / window): 5 VALU per score instead of ~14 -- the softmax, not the MFMA,
@@ -291,10 +307,9 @@ __global__ __launch_bounds__(64 * (PF_BM / (16 * MT)), 2) void prefill_kernel(co
     for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) s[nt][mt] = (f32x4){0, 0, 0, 0};
-      const int tok = 16 * nt + c16;
 #pragma unroll
       for (int ks = 0; ks < QK_STEPS; ++ks) {
-        const uint4 kf = *reinterpret_cast<const uint4*>(k_slot(tok, 4 * ks + g4));
+        const uint4 kf = *reinterpret_cast<const uint4*>(k_frag[ks] + 16 * nt * KROW);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) s[nt][mt] = Mma<T>::mfma(kf, qf[mt][ks], s[nt][mt]);
       }
@@ -372,9 +387,8 @@ __global__ __launch_bounds__(64 * (PF_BM / (16 * MT)), 2) void prefill_kernel(co
       if (is_ctx) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const int d = 16 * dt + c16;
-          const uint2 va = *reinterpret_cast<const uint2*>(v_slot(d, 2 * ta + (g4 >> 1)) + (g4 & 1) * 8);
-          const uint2 vb = *reinterpret_cast<const uint2*>(v_slot(d, 2 * tb + (g4 >> 1)) + (g4 & 1) * 8);
+          const uint2 va = *reinterpret_cast<const uint2*>(v_frag[ta] + 16 * dt * VROW);
+          const uint2 vb = *reinterpret_cast<const uint2*>(v_frag[tb] + 16 * dt * VROW);
           const uint4 vf = make_uint4(va.x, va.y, vb.x, vb.y);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) o[dt][mt] = Mma<T>::mfma(vf, pb[mt], o[dt][mt]);
@@ -384,12 +398,10 @@ __global__ __launch_bounds__(64 * (PF_BM / (16 * MT)), 2) void prefill_kernel(co
         // 16 t + 4 g4 + (0..3) x d 16 dt + (0..15); lane 4q+p addresses token q, d 4p..4p+3 and
         // lane c16 receives d = 16 dt + c16 of the four tokens: the V^T fragment, transposed
         // by the hardware.  All 64 lanes are active here (the instruction requires it).
-        const int tq = 4 * g4 + (c16 >> 2);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const uint8_t* va_p = vn_slot(16 * ta + tq, 2 * dt + ((c16 >> 1) & 1)) + (c16 & 1) * 8;
-          const uint8_t* vb_p = vn_slot(16 * tb + tq, 2 * dt + ((c16 >> 1) & 1)) + (c16 & 1) * 8;
-          const uint2 va = lds_read_tr16(va_p), vb = lds_read_tr16(vb_p);
+          const uint2 va = lds_read_tr16(vn_frag[dt] + 16 * ta * KROW);
+          const uint2 vb = lds_read_tr16(vn_frag[dt] + 16 * tb * KROW);
           const uint4 vf = make_uint4(va.x, va.y, vb.x, vb.y);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) o[dt][mt] = Mma<T>::mfma(vf, pb[mt], o[dt][mt]);
@@ -464,23 +476,36 @@ __global__ __launch_bounds__(64 * (PF_BM / (16 * MT)), 2) void prefill_kernel(co
   }
 }
 
-template <typename T, bool FP8, int D>
-static void launch_bs(const PrefillParams& p, int block_size, dim3 grid, hipStream_t st) {
-  // head sizes >= 96 do not fit two query tiles per wave in 256 VGPRs without spilling
-  constexpr int MT = D >= 96 ? 1 : 2;
-  constexpr int THREADS = 64 * (PF_BM / (16 * MT));
+template <typename T, bool FP8, int D, int MT, int NW>
+static void launch_cfg(const PrefillParams& p, int block_size, int max_input_len, int num_heads,
+                       int batch, hipStream_t st) {
+  constexpr int BM = 16 * MT * NW;
+  const dim3 grid((max_input_len + BM - 1) / BM, num_heads, batch);
   if (block_size == 16)
-    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 16, MT>), grid, dim3(THREADS), 0, st, p);
+    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 16, MT, NW>), grid, dim3(64 * NW), 0, st, p);
   else
-    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 32, MT>), grid, dim3(THREADS), 0, st, p);
+    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 32, MT, NW>), grid, dim3(64 * NW), 0, st, p);
+}
+template <typename T, bool FP8, int D>
+static void launch_bs(const PrefillParams& p, int block_size, int max_input_len, int num_heads,
+                      int batch, hipStream_t st) {
+  // head sizes >= 96 do not fit two query tiles per wave in 256 VGPRs without spilling
+  if constexpr (D >= 96) {
+    if (g_pf_rows == 128) launch_cfg<T, FP8, D, 1, 8>(p, block_size, max_input_len, num_heads, batch, st);
+    else launch_cfg<T, FP8, D, 1, 4>(p, block_size, max_input_len, num_heads, batch, st);
+  } else {
+    if (g_pf_rows == 64) launch_cfg<T, FP8, D, 2, 2>(p, block_size, max_input_len, num_heads, batch, st);
+    else launch_cfg<T, FP8, D, 2, 4>(p, block_size, max_input_len, num_heads, batch, st);
+  }
 }
 template <typename T, bool FP8>
-static void launch_d(const PrefillParams& p, int head_size, int block_size, dim3 grid, hipStream_t st) {
+static void launch_d(const PrefillParams& p, int head_size, int block_size, int max_input_len,
+                     int num_heads, int batch, hipStream_t st) {
   switch (head_size) {
-    case 32: launch_bs<T, FP8, 32>(p, block_size, grid, st); break;
-    case 64: launch_bs<T, FP8, 64>(p, block_size, grid, st); break;
-    case 96: launch_bs<T, FP8, 96>(p, block_size, grid, st); break;
-    default: launch_bs<T, FP8, 128>(p, block_size, grid, st); break;
+    case 32: launch_bs<T, FP8, 32>(p, block_size, max_input_len, num_heads, batch, st); break;
+    case 64: launch_bs<T, FP8, 64>(p, block_size, max_input_len, num_heads, batch, st); break;
+    case 96: launch_bs<T, FP8, 96>(p, block_size, max_input_len, num_heads, batch, st); break;
+    default: launch_bs<T, FP8, 128>(p, block_size, max_input_len, num_heads, batch, st); break;
   }
 }
 
@@ -541,14 +566,13 @@ extern "C" int vllm_amd_context_attention_fwd(
   p.sm_scale = sm_scale;
   p.sliding_window = sliding_window > 0 ? sliding_window : 0;
   p.skip_decode = skip_decode;
-  const dim3 grid((max_input_len + PF_BM - 1) / PF_BM, num_heads, batch);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VLLM_AMD_BF16) {
-    if (es == 2) launch_d<bf16_t, false>(p, head_size, block_size, grid, st);
-    else launch_d<bf16_t, true>(p, head_size, block_size, grid, st);
+    if (es == 2) launch_d<bf16_t, false>(p, head_size, block_size, max_input_len, num_heads, batch, st);
+    else launch_d<bf16_t, true>(p, head_size, block_size, max_input_len, num_heads, batch, st);
   } else {
-    if (es == 2) launch_d<f16_t, false>(p, head_size, block_size, grid, st);
-    else launch_d<f16_t, true>(p, head_size, block_size, grid, st);
+    if (es == 2) launch_d<f16_t, false>(p, head_size, block_size, max_input_len, num_heads, batch, st);
+    else launch_d<f16_t, true>(p, head_size, block_size, max_input_len, num_heads, batch, st);
   }
   VA_LAUNCH_CHECK(op);
   return VLLM_AMD_OK;
