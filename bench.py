@@ -244,6 +244,37 @@ def run_fused_neighbours(device, iters=20):
     return out
 
 
+def run_prefill(device, iters=5):
+    """context_attention_fwd (chunked prefill over a paged fp8 prefix) at the
+    Llama-3-8B head shape; flops = 4 D H sum_seq q_len (ctx + (q_len + 1) / 2) against the bf16
+    dense MFMA peak."""
+    from vllm_amd.attention.ops import context_attention_fwd
+    H, KVH, D, BS = 32, 8, 128, 16
+    out = {}
+    for (B, ql, cl) in ((4, 2048, 2048), (1, 8192, 0), (64, 128, 4096)):
+        T = B * ql
+        g = torch.Generator(device=device).manual_seed(0)
+        q = (torch.rand((T, H, D), device=device, generator=g) - 0.5).to(torch.bfloat16)
+        k = (torch.rand((T, KVH, D), device=device, generator=g) - 0.5).to(torch.bfloat16)
+        v = (torch.rand((T, KVH, D), device=device, generator=g) - 0.5).to(torch.bfloat16)
+        o = torch.empty_like(q)
+        nb = (cl + BS - 1) // BS + 1
+        kc = torch.randint(0, 120, (B * nb, KVH, D // 16, BS, 16), device=device, dtype=torch.uint8)
+        vc = torch.randint(0, 120, (B * nb, KVH, D, BS), device=device, dtype=torch.uint8)
+        b_loc = torch.randperm(B * nb, device=device).to(torch.int32).view(B, nb)
+        start = (torch.arange(B + 1, device=device) * ql).to(torch.int32)
+        seql = torch.full((B,), ql + cl, dtype=torch.int32, device=device)
+        sc = torch.full((1,), 0.02, device=device)
+        fn = lambda: context_attention_fwd(q, k, v, o, "fp8", kc, vc, b_loc, start, seql, ql + cl,
+                                           ql, sc, sc)
+        t = time_gpu_graph(fn, iters)
+        flops = 4.0 * D * H * B * ql * (cl + (ql + 1) / 2)
+        out[f"B{B}_q{ql}_ctx{cl}_fp8kv"] = dict(us=round(t * 1e6, 1),
+                                                tflops=round(flops / t / 1e12, 1),
+                                                frac_of_bf16_peak=round(flops / t / 2.5e15, 4))
+    return out
+
+
 def cpu_baseline():
     """Reference CPU paged_attention_v1 on BASELINE.json configs[0] (32 seqs, ctx 1024,
     32q/8kv, d 128, block 16, bf16 KV), all host cores available to this process."""
@@ -370,6 +401,7 @@ def main():
             extra["scaled_mm_pct_of_fp8_peak"] = round(100 * best["tflops"] / FP8_DENSE_PEAK_TFLOPS, 2)
             extra["cache_quant"] = run_cache_quant(device)
             extra["fused_neighbours"] = run_fused_neighbours(device)
+            extra["prefill_attention"] = run_prefill(device)
             line["cpu_baseline"] = cpu_baseline()
         line["extra"] = extra
     if world > 1:

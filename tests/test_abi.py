@@ -20,7 +20,7 @@ def declared_symbols():
 def test_library_exports_every_declared_symbol():
     from vllm_amd import _lib
     syms = declared_symbols()
-    assert len(syms) >= 21
+    assert len(syms) >= 22
     for s in syms:
         assert hasattr(_lib.lib, s), f"{s} declared in include/vllm_amd.h but not exported"
     # and the ctypes signatures cover every entry point that takes arguments
