@@ -135,3 +135,15 @@ def test_prefill_large_matches_torch():
     ref = prefill_reference({k: ([t.cuda() for t in v] if isinstance(v, list) and torch.is_tensor(v[0])
                                  else (v.cuda() if torch.is_tensor(v) else v)) for k, v in c.items()})
     torch.testing.assert_close(out.float(), ref.cpu(), atol=6e-3, rtol=0)
+
+
+def test_forward_prefix_wrapper(oracle):
+    """PagedAttention.forward_prefix (paged_attn.py:196-239) allocates the output and forwards."""
+    from vllm_amd.attention import PagedAttention
+    c = make_prefill_case([40, 9], [33, 70], 4, 2, 64, 16, torch.float16, "auto", seed=4)
+    one = torch.ones(1, device="cuda")
+    out = PagedAttention.forward_prefix(c["q"].cuda(), c["k"].cuda(), c["v"].cuda(), "auto",
+                                        c["k_cache"].cuda(), c["v_cache"].cuda(), c["b_loc"].cuda(),
+                                        c["b_start_loc"].cuda(), c["b_seq_len"].cuda(),
+                                        c["max_input_len"], None, None, one, one)
+    torch.testing.assert_close(out.cpu().float(), prefill_reference(c), atol=1.5e-3, rtol=0)

@@ -1,8 +1,7 @@
 """Host-side mirror of the reference's ``PagedAttention`` helper
 (vllm/attention/ops/paged_attn.py:36-256): KV-cache shape / split, cache write
-and the v1/v2 decode heuristic with the reference's buffer shapes.  Only the
-decode half is in scope (prefill `forward_prefix` is a Triton kernel in the
-reference and out of scope)."""
+the v1/v2 decode heuristic with the reference's buffer shapes, and
+`forward_prefix` (a Triton kernel in the reference, a HIP kernel here: SURVEY.md 8f-4)."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -116,6 +115,20 @@ class PagedAttention:
                                  value_cache, num_kv_heads, scale, block_tables, seq_lens,
                                  query_start_loc, block_size, max_seq_len, alibi_slopes,
                                  kv_cache_dtype, k_scale, v_scale, fp8_out_scale)
+        return output
+
+    @staticmethod
+    def forward_prefix(query, key, value, kv_cache_dtype: str, key_cache, value_cache,
+                       block_tables, query_start_loc, seq_lens_tensor, max_query_len: int,
+                       alibi_slopes: Optional[torch.Tensor], sliding_window: Optional[int],
+                       k_scale: torch.Tensor, v_scale: torch.Tensor) -> torch.Tensor:
+        """paged_attn.py:196-239: chunked prefill over the cached prefix (HIP kernel instead of
+        the reference's Triton context_attention_fwd)."""
+        from .ops.prefix_prefill import context_attention_fwd
+        output = torch.empty_like(query)
+        context_attention_fwd(query, key, value, output, kv_cache_dtype, key_cache, value_cache,
+                              block_tables, query_start_loc, seq_lens_tensor, None, max_query_len,
+                              k_scale, v_scale, alibi_slopes, sliding_window)
         return output
 
     @staticmethod
