@@ -75,8 +75,19 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, g4 = lane >> 4;
-  // causal: row blocks further down have more KV tiles -> launch them first
-  const int start_m = gridDim.x - 1 - blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
+  // Workgroup order.  Consecutive hardware ids go to different XCDs (id % 8), each with its own
+  // L2; the row blocks and GQA heads that read the SAME K/V must share one, or every XCD streams
+  // the same K/V from HBM.  The bijective remap gives each XCD a contiguous range of logical
+  // ids; within it row blocks vary fastest, then heads, then sequences (+54 % on pure prefill).
+  // Causal: later row blocks have more KV tiles and start first.
+  int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  {
+    const int nwg = gridDim.x * gridDim.y * gridDim.z;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
+    wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  const int start_m = gridDim.x - 1 - wg % gridDim.x;
+  const int head = (wg / gridDim.x) % gridDim.y, seq = wg / (gridDim.x * gridDim.y);
   const int kvh = head / (p.num_heads / p.num_kv_heads);
 
   const int seq_len = p.b_seq_len[seq];
