@@ -274,7 +274,8 @@ int vllm_amd_swap_blocks(const void* src, void* dst, int64_t block_bytes,
  *                     as in the reference's alibi kernel)
  *   fp8_out_scale     float[1] or NULL: o is e4m3 bytes = clamp(acc / l / scale)
  *   sliding_window    <= 0 disables; skip_decode: sequences with one query token are skipped
- * Supported here: f16 / bf16 queries, head_size 32/64/96/128, block_size 16/32,
+ * Supported here: f16 / bf16 queries, head_size a multiple of 8 (16 with an fp8 cache) up to
+ * 128 (padded to a multiple of 32 inside the kernel), block_size 16/32,
  * kv_cache_dtype auto / fp8_e4m3. */
 int vllm_amd_context_attention_fwd(
     void* o, const void* q, const void* k, const void* v, const void* k_cache,

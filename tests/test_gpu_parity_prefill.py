@@ -82,6 +82,20 @@ def test_prefill_alibi(oracle, dtype, kv):
     torch.testing.assert_close(out.float(), prefill_reference(c, 0, slopes), atol=tol(dtype), rtol=0)
 
 
+@pytest.mark.parametrize("head_size", [24, 40, 80, 112, 120])   # test_prefix_prefill.py:23 has 24
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+def test_prefill_padded_head_sizes(oracle, head_size, kv):
+    """Head sizes that are not a multiple of the MFMA K step are zero-padded inside the kernel."""
+    if kv == "fp8" and head_size % 16:
+        pytest.skip("fp8 cache layout needs head_size % 16 == 0 (x = 16)")
+    c = make_prefill_case([1, 90, 130], [70, 0, 45], 4, 2, head_size, 16, torch.float16, kv,
+                          seed=head_size, kv_scale=0.02)
+    out = run(c, kv)
+    assert not out.isnan().any()
+    torch.testing.assert_close(out.float(), run_oracle(oracle, c, kv).float(), atol=1.5e-3, rtol=0)
+    torch.testing.assert_close(out.float(), prefill_reference(c), atol=1.5e-3, rtol=0)
+
+
 def test_prefill_skip_decode_and_strides(oracle):
     """skip_decode leaves single-token sequences untouched (:104-105); q / k / v / o may be
     strided views (qkv slices of one projection output)."""

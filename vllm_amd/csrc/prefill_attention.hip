@@ -33,6 +33,7 @@ struct PrefillParams {
   const float* k_scale; const float* v_scale; const float* alibi_slopes;
   const float* fp8_out_scale;
   int num_heads, num_kv_heads;
+  int head_size;   // real head size; the kernel template is padded to a multiple of 32
   int64_t b_loc_stride, q_stride_t, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h,
       o_stride_t, o_stride_h, kc_block_bytes, kc_head_bytes, vc_block_bytes, vc_head_bytes;
   float sm_scale; int sliding_window; int skip_decode;
@@ -53,6 +54,9 @@ template <typename T, bool FP8, int D, int BS, int MT, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams p) {
   constexpr int PF_THREADS = 64 * NW, PF_BM = 16 * MT * NW;
   static_assert(D % 32 == 0 && D <= 128, "");
+  // D = head size padded to a multiple of 32: chunks at d >= dr are staged as zeros (K, Q: no
+  // contribution to the scores; V: output columns that are never stored)
+  const int dr = p.head_size;
   constexpr int KCH = D / 8;                 // 16-byte chunks per K row (8 elements each)
   constexpr int KROW = D * 2;                // bytes per K row in LDS
   constexpr int KSWZ = (KCH % 16 == 0) ? 15 : (KCH % 8 == 0) ? 7 : 3;   // chunk ^= tok & KSWZ
@@ -114,8 +118,9 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
                   (int64_t)head * p.q_stride_h;
 #pragma unroll
     for (int ks = 0; ks < QK_STEPS; ++ks) {
-      const uint4 v = *reinterpret_cast<const uint4*>(qp + 32 * ks + 8 * g4);
-      qf[mt][ks] = m < qlen ? v : make_uint4(0, 0, 0, 0);
+      const int d0 = 32 * ks + 8 * g4;
+      const uint4 v = *reinterpret_cast<const uint4*>(qp + (d0 < dr ? d0 : 0));
+      qf[mt][ks] = (m < qlen && d0 < dr) ? v : make_uint4(0, 0, 0, 0);
     }
   }
 
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
         static_for<K16_ITEMS>([&](auto ic_) {
           constexpr int i = decltype(ic_)::value;          // item -> (tok = item & 63, chunk)
           const int item = min(tid + PF_THREADS * i, K16_TOTAL - 1);
-          const int tok = item & 63, c = item >> 6;
+          const int tok = item & 63, c = min(item >> 6, dr / 8 - 1);
           const uint8_t* src = p.k_cache + (int64_t)pg.k * p.kc_block_bytes +
                                (int64_t)kvh * p.kc_head_bytes + ((c * BS + tok % BS) << 4);
           kst[i] = *reinterpret_cast<const u32x4*>(src);
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
           constexpr int i = decltype(ic_)::value;          // item -> (page, d, 8-token chunk of the page)
           const int item = min(tid + PF_THREADS * i, V16_TOTAL - 1);
           constexpr int CPP = BS / 8;
-          const int j = item % CPP, d = (item / CPP) % D;
+          const int j = item % CPP, d = min((item / CPP) % D, dr - 1);
           const uint8_t* src = p.v_cache + (int64_t)pg.v[i] * p.vc_block_bytes +
                                (int64_t)kvh * p.vc_head_bytes + ((d * BS + 8 * j) << 1);
           vst[i] = *reinterpret_cast<const u32x4*>(src);
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
         static_for<K8_ITEMS>([&](auto ic_) {
           constexpr int i = decltype(ic_)::value;           // item -> (tok, 16-element chunk)
           const int item = tid + PF_THREADS * i;
-          const int tok = item & 63, cc = min(item >> 6, D / 16 - 1);
+          const int tok = item & 63, cc = min(item >> 6, dr / 16 - 1);
           const uint8_t* src = p.k_cache + (int64_t)pg.k * p.kc_block_bytes +
                                (int64_t)kvh * p.kc_head_bytes + ((cc * BS + tok % BS) << 4);
           kst[i] = *reinterpret_cast<const u32x4*>(src);
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
           constexpr int i = decltype(ic_)::value;           // item -> (page, d, 16-token chunk)
           const int item = tid + PF_THREADS * i;
           constexpr int CPP = BS / 16;
-          const int j = item % CPP, d = (item / CPP) % D;
+          const int j = item % CPP, d = min((item / CPP) % D, dr - 1);
           const uint8_t* src = p.v_cache + (int64_t)pg.v[i] * p.vc_block_bytes +
                                (int64_t)kvh * p.vc_head_bytes + (d * BS + 16 * j);
           vst[i] = *reinterpret_cast<const u32x4*>(src);
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
       static_for<K16_ITEMS>([&](auto ic_) {
         constexpr int i = decltype(ic_)::value;            // item -> (tok, chunk) for K and for V
         const int item = min(tid + PF_THREADS * i, K16_TOTAL - 1);
-        const int tok = item & 63, c = item >> 6;
+        const int tok = item & 63, c = min(item >> 6, dr / 8 - 1);
         const int64_t row = tok0 + min(n0 + tok, qlen - 1);
         kst[i] = *reinterpret_cast<const u32x4*>((const T*)p.k + row * p.k_stride_t +
                                                  (int64_t)kvh * p.k_stride_h + 8 * c);
@@ -234,7 +239,8 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
         static_for<K16_ITEMS>([&](auto ic_) {
           constexpr int i = decltype(ic_)::value;
           const int item = tid + PF_THREADS * i;
-          if (item < K16_TOTAL) *reinterpret_cast<u32x4*>(k_slot(item & 63, item >> 6)) = kst[i];
+          if (item < K16_TOTAL)
+            *reinterpret_cast<u32x4*>(k_slot(item & 63, item >> 6)) = (item >> 6) < dr / 8 ? kst[i] : (u32x4){0, 0, 0, 0};
         });
         static_for<V16_ITEMS>([&](auto ic_) {
           constexpr int i = decltype(ic_)::value;
@@ -243,7 +249,8 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
           const int j = item % CPP, d = (item / CPP) % D, pg = item / (CPP * D);
           // stale cache bytes of tokens >= ctx may be NaN, and 0 * NaN = NaN in the PV product
           const int n = t * PF_BN + pg * BS + 8 * j;
-          if (item < V16_TOTAL) *reinterpret_cast<uint4*>(v_slot(d, pg * CPP + j)) = mask_halfs(as_u4(vst[i]), ctx - n);
+          if (item < V16_TOTAL)
+            *reinterpret_cast<uint4*>(v_slot(d, pg * CPP + j)) = mask_halfs(as_u4(vst[i]), d < dr ? ctx - n : 0);
         });
       } else {
         static_for<K8_ITEMS>([&](auto ic_) {
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
           const int tok = item & 63, cc = item >> 6;
           if (cc < D / 16) {
             uint4 lo, hi;   // exact widening; k_scale is applied to the scores
-            widen16<T>(as_u4(kst[i]), lo, hi);
+            widen16<T>(as_u4(cc < dr / 16 ? kst[i] : (u32x4){0, 0, 0, 0}), lo, hi);
             *reinterpret_cast<uint4*>(k_slot(tok, 2 * cc)) = lo;
             *reinterpret_cast<uint4*>(k_slot(tok, 2 * cc + 1)) = hi;
           }
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
           const int j = item % CPP, d = (item / CPP) % D, pg = item / (CPP * D);
           const int tc = (pg * BS + 16 * j) >> 3;
           if (item < 4 * D) {
-            const uint4 raw = mask_bytes(as_u4(vst[i]), ctx - (t * PF_BN + pg * BS + 16 * j));
+            const uint4 raw = mask_bytes(as_u4(vst[i]), d < dr ? ctx - (t * PF_BN + pg * BS + 16 * j) : 0);
             uint4 lo, hi;   // exact widening; v_scale is applied to the probabilities
             widen16<T>(raw, lo, hi);
             *reinterpret_cast<uint4*>(v_slot(d, tc)) = lo;
@@ -278,9 +285,9 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
         const int item = tid + PF_THREADS * i;
         const int tok = item & 63, c = item >> 6;
         if (item < K16_TOTAL) {
-          *reinterpret_cast<u32x4*>(k_slot(tok, c)) = kst[i];
+          *reinterpret_cast<u32x4*>(k_slot(tok, c)) = c < dr / 8 ? kst[i] : (u32x4){0, 0, 0, 0};
           *reinterpret_cast<u32x4*>(vn_slot(tok, c)) =
-              (t - ctx_tiles) * PF_BN + tok < qlen ? vst[i] : (u32x4){0, 0, 0, 0};
+              ((t - ctx_tiles) * PF_BN + tok < qlen && c < dr / 8) ? vst[i] : (u32x4){0, 0, 0, 0};
         }
       });
     }
@@ -468,6 +475,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
       T* op = (T*)p.o + (int64_t)(tok0 + m) * p.o_stride_t + (int64_t)head * p.o_stride_h;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
+        if (16 * dt + 4 * g4 >= dr) continue;
         const uint2 w = make_uint2(Mma<T>::pack2(o[dt][mt][0] * inv, o[dt][mt][1] * inv),
                                    Mma<T>::pack2(o[dt][mt][2] * inv, o[dt][mt][3] * inv));
         *reinterpret_cast<uint2*>(op + 16 * dt + 4 * g4) = w;
@@ -477,6 +485,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
       uint8_t* op = (uint8_t*)p.o + (int64_t)(tok0 + m) * p.o_stride_t + (int64_t)head * p.o_stride_h;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
+        if (16 * dt + 4 * g4 >= dr) continue;
         float y[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -512,7 +521,7 @@ static void launch_bs(const PrefillParams& p, int block_size, int max_input_len,
 template <typename T, bool FP8>
 static void launch_d(const PrefillParams& p, int head_size, int block_size, int max_input_len,
                      int num_heads, int batch, hipStream_t st) {
-  switch (head_size) {
+  switch ((head_size + 31) / 32 * 32) {   // padded to the MFMA K step
     case 32: launch_bs<T, FP8, 32>(p, block_size, max_input_len, num_heads, batch, st); break;
     case 64: launch_bs<T, FP8, 64>(p, block_size, max_input_len, num_heads, batch, st); break;
     case 96: launch_bs<T, FP8, 96>(p, block_size, max_input_len, num_heads, batch, st); break;
@@ -543,9 +552,11 @@ extern "C" int vllm_amd_context_attention_fwd(
              "%s: query dtype must be float16 or bfloat16", op);
   VA_REQUIRE(kv_cache_dtype == VLLM_AMD_KV_AUTO || kv_cache_dtype == VLLM_AMD_KV_FP8_E4M3,
              VLLM_AMD_EUNSUPPORTED, "Unsupported FP8 dtype: %d", kv_cache_dtype);
-  VA_REQUIRE(head_size == 32 || head_size == 64 || head_size == 96 || head_size == 128,
-             VLLM_AMD_EUNSUPPORTED, "%s: unsupported head size: %d (32, 64, 96, 128)", op,
-             head_size);
+  VA_REQUIRE(head_size >= 8 && head_size <= 128 &&
+                 head_size % (kv_cache_dtype == VLLM_AMD_KV_AUTO ? 8 : 16) == 0,
+             VLLM_AMD_EUNSUPPORTED,
+             "%s: unsupported head size: %d (multiples of 8, of 16 with an fp8 cache, up to 128)",
+             op, head_size);
   VA_REQUIRE(block_size == 16 || block_size == 32, VLLM_AMD_EUNSUPPORTED,
              "%s: unsupported block size: %d (16, 32)", op, block_size);
   VA_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, VLLM_AMD_EINVAL,
@@ -567,6 +578,7 @@ extern "C" int vllm_amd_context_attention_fwd(
   p.k_scale = k_scale; p.v_scale = v_scale; p.alibi_slopes = alibi_slopes;
   p.fp8_out_scale = fp8_out_scale;
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
+  p.head_size = head_size;
   p.b_loc_stride = b_loc_stride;
   p.q_stride_t = q_stride_t; p.q_stride_h = q_stride_h;
   p.k_stride_t = k_stride_t; p.k_stride_h = k_stride_h;
