@@ -335,7 +335,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # VLLM_AMD_BENCH_DIST=1 exercises the distributed path with a single rank (rehearsal of the
+    # N > 1 launch on a one-GPU box)
+    use_dist = world > 1 or os.environ.get("VLLM_AMD_BENCH_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist  # noqa
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -349,7 +352,7 @@ def main():
     cfg = dict(S=64, ctx=4096, H=32, KVH=8, D=128, BS=16, kv="fp8")
     r = run_attention(cfg, args.steps, args.warmup, device, dist)
     wall = r["wall"]
-    if world > 1:
+    if use_dist:
         t = torch.tensor([wall, r["event"]], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ev = t.tolist()
@@ -404,7 +407,7 @@ def main():
             extra["prefill_attention"] = run_prefill(device)
             line["cpu_baseline"] = cpu_baseline()
         line["extra"] = extra
-    if world > 1:
+    if use_dist:
         from vllm_amd.distributed import bench_row_parallel
         try:
             rp = bench_row_parallel(device, dist)
@@ -415,7 +418,7 @@ def main():
         dist.barrier()
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
