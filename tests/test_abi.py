@@ -130,3 +130,44 @@ def test_torch_layer_rejects_cpu_tensors_and_bad_strings():
     with pytest.raises(RuntimeError, match="Unsupported data type of kv cache: fp8_e5m2"):
         _torch_ops._kv("fp8_e5m2")
     assert ops.FP8_DTYPE == torch.float8_e4m3fn
+
+
+def test_validation_errors_of_the_neighbour_ops():
+    """Same host-side validation for the SURVEY 8f entry points: nothing is launched."""
+    from vllm_amd import _lib
+    L = _lib.lib
+    p = 0x1000
+    # fused norm / activation quant
+    assert L.vllm_amd_rms_norm_static_fp8_quant(p, p, p, p, 1e-6, 0, 4096, 4096, _lib.BF16, None) == 0
+    assert "unsupported input dtype" in _err(
+        L.vllm_amd_rms_norm_static_fp8_quant(p, p, p, p, 1e-6, 4, 4096, 4096, 9, None))
+    assert "input stride" in _err(
+        L.vllm_amd_rms_norm_static_fp8_quant(p, p, p, p, 1e-6, 4, 4096, 1024, _lib.BF16, None))
+    assert "null scale or residual" in _err(
+        L.vllm_amd_fused_add_rms_norm_static_fp8_quant(p, p, None, p, p, 1e-6, 4, 64, 64, _lib.BF16, None))
+    assert "null scales" in _err(
+        L.vllm_amd_rms_norm_dynamic_per_token_quant(p, p, p, None, 1e-6, None, None, 4, 64, _lib.BF16, None))
+    assert "float16 or bfloat16" in _err(L.vllm_amd_silu_and_mul_quant(p, p, p, 4, 64, _lib.F32, None))
+    assert L.vllm_amd_silu_and_mul_quant(p, p, p, 0, 64, _lib.BF16, None) == 0
+    # slot mapping / swap
+    assert "must be positive" in _err(L.vllm_amd_compute_slot_mapping(p, p, p, p, 4, 8, 0, None))
+    assert L.vllm_amd_compute_slot_mapping(p, p, p, p, 0, 8, 16, None) == 0
+    assert L.vllm_amd_swap_blocks(p, p, 4096, p, 0, None) == 0
+    assert "null pointer" in _err(L.vllm_amd_swap_blocks(p, p, 4096, None, 2, None))
+
+    # prefill attention
+    def pf(head_size=128, block_size=16, dtype=_lib.BF16, kv=_lib.KV_AUTO, heads=8, kvh=2, batch=1,
+           qs=1024):
+        return L.vllm_amd_context_attention_fwd(
+            p, p, p, p, p, p, p, p, p, p, p, None, None, batch, heads, kvh, head_size, block_size,
+            128, 16, qs, head_size, kvh * head_size, head_size, kvh * head_size, head_size,
+            heads * head_size, head_size, kvh * head_size * block_size, head_size * block_size,
+            kvh * head_size * block_size, head_size * block_size, 0.1, 0, 0, dtype, kv, None)
+    assert pf(batch=0) == 0
+    assert "unsupported head size: 256" in _err(pf(head_size=256))
+    assert "unsupported head size: 24" in _err(pf(head_size=24, kv=_lib.KV_FP8_E4M3, qs=192))
+    assert "unsupported block size: 8" in _err(pf(block_size=8))
+    assert "float16 or bfloat16" in _err(pf(dtype=_lib.F32))
+    assert "Unsupported FP8 dtype" in _err(pf(kv=5))
+    assert "multiple of num_kv_heads" in _err(pf(heads=8, kvh=3))
+    assert "16-byte aligned" in _err(pf(qs=1021))
