@@ -300,7 +300,11 @@ int vllm_amd_context_attention_fwd(
 /*                 staged 128x128 tile, 2..10 = direct-to-LDS tile shapes       */
 /*                 (256x256, 128x128, 128x64, 64x64, 64x32; even ids 4..10      */
 /*                 take 2 or 4 K blocks per barrier; scaled_mm_large.hip),      */
-/*                 11 = weight-streaming kernel (M <= 32 only)                  */
+/*                 11 = weight-streaming kernel (M <= 32 only),                 */
+/*                 12, 13 = 32x128 tile (1 / 2 K blocks per barrier)            */
+/*   "mm_splitk":  K slices per output tile of the direct-to-LDS kernels        */
+/*                 (0 = heuristic, 1 = never split, n = n slices; reduced       */
+/*                 inside the kernel through a per-device fp32 workspace)       */
 /* ------------------------------------------------------------------------- */
 int vllm_amd_set_tuning(const char* key, int value);
 

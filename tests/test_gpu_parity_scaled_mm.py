@@ -90,11 +90,16 @@ def test_wvSplitKQ(ops, oracle, n, mk):
 def force_kernel():
     """Pin the GEMM kernel choice (vllm_amd_set_tuning "mm_kernel"); back to auto afterwards."""
     from vllm_amd import _lib
-    yield lambda k: _lib.set_tuning("mm_kernel", k)
+
+    def force(k, splits=0):
+        _lib.set_tuning("mm_kernel", k)
+        _lib.set_tuning("mm_splitk", splits)
+    yield force
     _lib.set_tuning("mm_kernel", 0)
+    _lib.set_tuning("mm_splitk", 0)
 
 
-@pytest.mark.parametrize("kernel", list(range(1, 12)))
+@pytest.mark.parametrize("kernel", list(range(1, 14)))
 @pytest.mark.parametrize("MNK", [(300, 520, 256), (256, 256, 1024), (257, 971, 384), (640, 1288, 2048),
                                  (40, 8, 128 * 3), (5, 264, 512), (32, 1040, 1024)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
@@ -107,7 +112,7 @@ def test_scaled_mm_every_tile_kernel(ops, oracle, force_kernel, kernel, MNK, out
     check(ops, oracle, M, N, K, False, False, out_dtype, bias=False, seed=M + N + kernel)
 
 
-@pytest.mark.parametrize("kernel", list(range(1, 11)))
+@pytest.mark.parametrize("kernel", list(range(1, 11)) + [12, 13])
 def test_scaled_mm_integer_exact_every_kernel(ops, force_kernel, kernel):
     M, N, K = 512, 768, 640
     g = torch.Generator().manual_seed(kernel)
@@ -134,3 +139,64 @@ def test_scaled_mm_large_auto(ops):
     out = ops.cutlass_scaled_mm(a, w.t(), sa, sb, torch.bfloat16)
     ref = (K * sa * sb.t()).to(torch.bfloat16)
     assert torch.equal(out, ref)
+
+
+SPLIT_KERNELS = [3, 4, 5, 6, 7, 8, 9, 10, 12, 13]
+
+
+@pytest.mark.parametrize("kernel", SPLIT_KERNELS)
+@pytest.mark.parametrize("splits", [2, 3, 8])
+@pytest.mark.parametrize("MNK", [(300, 520, 1024), (33, 264, 128 * 7), (70, 1288, 2048), (16, 4096, 4096)])
+def test_scaled_mm_split_k(ops, oracle, force_kernel, kernel, splits, MNK):
+    """Split-K (K slices reduced in-kernel through the fp32 workspace): every tile shape,
+    slice counts that do and do not divide the number of K blocks, ragged edge tiles."""
+    M, N, K = MNK
+    force_kernel(kernel, splits)
+    check(ops, oracle, M, N, K, True, True, torch.bfloat16, bias=(kernel % 2 == 0), seed=M + kernel + splits)
+    check(ops, oracle, M, N, K, False, True, torch.float16, bias=False, seed=N + kernel + splits)
+
+
+@pytest.mark.parametrize("kernel", SPLIT_KERNELS)
+def test_scaled_mm_split_k_integer_exact_and_repeatable(ops, force_kernel, kernel):
+    """Integer operands: bit-exact for any slice count; random operands: the slices are
+    summed in slice order whoever arrives last, so repeated launches (which also reuse the
+    self-resetting ticket counters) agree to the bit."""
+    M, N, K = 200, 776, 2560
+    g = torch.Generator().manual_seed(kernel)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    one = torch.ones((1, 1)).cuda()
+    a8, w8 = a.to(torch.float8_e4m3fn).cuda(), w.to(torch.float8_e4m3fn).cuda()
+    ref = (a @ w.t()).to(torch.float16).float()
+    for splits in (2, 4, 5, 20):
+        force_kernel(kernel, splits)
+        out = ops.cutlass_scaled_mm(a8, w8.t(), one, one, torch.float16)
+        assert torch.equal(out.cpu().float(), ref), splits
+    ar, wr, sa, sb, _ = make(M, N, K, 7, True, True, torch.bfloat16, False)
+    ar, wr, sa, sb = ar.cuda(), wr.cuda(), sa.cuda(), sb.cuda()
+    force_kernel(kernel, 4)
+    outs = [ops.cutlass_scaled_mm(ar, wr.t(), sa, sb, torch.bfloat16) for _ in range(6)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+def test_scaled_mm_split_k_two_streams(ops, force_kernel):
+    """Launches on different streams use different workspaces."""
+    M, N, K = 64, 2048, 4096
+    ar, wr, sa, sb, _ = make(M, N, K, 11, True, True, torch.bfloat16, False)
+    ar, wr, sa, sb = ar.cuda(), wr.cuda(), sa.cuda(), sb.cuda()
+    force_kernel(9, 1)
+    ref = ops.cutlass_scaled_mm(ar, wr.t(), sa, sb, torch.bfloat16)
+    force_kernel(9, 4)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    res = []
+    for _ in range(8):
+        for st in (s1, s2):
+            with torch.cuda.stream(st):
+                res.append(ops.cutlass_scaled_mm(ar, wr.t(), sa, sb, torch.bfloat16))
+    torch.cuda.synchronize()
+    for o in res:
+        torch.testing.assert_close(o.float(), ref.float(), rtol=1.6e-2, atol=5e-3)
+        assert torch.equal(o, res[0])

@@ -270,9 +270,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void scaled_mm_skinny_kernel(
 void launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
                             const float* a_scales, const float* b_scales, const void* bias, int M,
                             int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int asn, int bsn,
-                            int out_dtype, bool vec, hipStream_t st);
+                            int out_dtype, bool vec, int splits, hipStream_t st);
 bool scaled_mm_large_fits(int M, int N, int K, int64_t lda, int64_t ldb);
-int g_mm_kernel = 0;   // tuning: 0 auto, 1 = register-staged 128x128, 2..10 = glds tile shapes
+int g_mm_kernel = 0;   // tuning: 0 auto, 1 = register-staged 128x128, 2..10, 12, 13 = glds tile shapes
+int g_mm_splitk = 0;   // tuning: 0 auto, n >= 1 = n K slices (1 = never split)
 }  // namespace va
 
 using namespace va;
@@ -298,7 +299,8 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
   // 64x32 direct-to-LDS tile is flat in M and faster (profiles/r01_gemm_sweep_small.csv).
   // "mm_kernel" 11 forces it.
   const bool skinny = g_mm_kernel == 11 ||
-                      (g_mm_kernel == 0 && (!glds_ok || (M <= 16 && ceil_div(N, 16) <= 256)));
+                      (g_mm_kernel == 0 &&
+                       (!glds_ok || (M <= (K >= 12288 ? 8 : 16) && ceil_div(N, 16) <= 256)));
   if (M <= 32 && skinny) {
     const int mt = ceil_div(M, 16);
 #define SK(T, MT)                                                                              \
@@ -321,7 +323,8 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
   const bool vec = (ldc % 4 == 0) && ((((uintptr_t)out) & 7) == 0);
   if (glds_ok) {
     int sel = g_mm_kernel;
-    if (sel == 0 || sel > 10) {
+    int splits = g_mm_splitk > 0 ? g_mm_splitk : 1;
+    if (sel == 0 || sel == 11 || sel > 13) {
       // Largest tile that still yields ~3/4 of a full wave of workgroups (256 CUs); rows of
       // a tile beyond M are wasted MFMA work, so BM <= 2 M.  With >= 1.5 waves of tiles the
       // variant that fits several workgroups per CU wins, below that the variant that takes
@@ -336,6 +339,12 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
         const int nt = ceil_div(M, t.bm) * ceil_div(N, t.bn);
         if (nt >= 190 || i == 4) {
           sel = (nt >= 384 || K % (128 * t.kb) != 0) ? t.id : t.id_kb;
+          // Even the smallest tile leaves half the CUs idle and the K loop is long: two K
+          // slices (in-kernel fix-up, scaled_mm_large.hip).  The fix-up is a chain of three
+          // device-scope round trips (~2.5 us), so it pays only here: 14336x4096, M 16..64:
+          // 17.2 -> 15.2 us; everywhere else on the grid splitting loses
+          // (profiles/r01_gemm_sweep_splitk.csv; at K = 8192 it is 11.5 vs 11.1 us).
+          if (i == 4 && nt <= 128 && K >= 12288 && g_mm_splitk == 0) splits = 2;
           break;
         }
       }
@@ -344,7 +353,7 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
       // 16-byte row-contiguous stores through LDS
       const bool vec16 = ldc % 8 == 0 && N % 8 == 0 && ((((uintptr_t)out) & 15) == 0);
       launch_scaled_mm_large(sel, out, a, b, a_scales, b_scales, bias, M, N, K,
-                             lda, ldb, ldc, a_scale_numel, b_scale_numel, out_dtype, vec16, st);
+                             lda, ldb, ldc, a_scale_numel, b_scale_numel, out_dtype, vec16, splits, st);
       VA_LAUNCH_CHECK(op);
       return VLLM_AMD_OK;
     }

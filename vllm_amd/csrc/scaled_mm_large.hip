@@ -30,6 +30,8 @@
 //     32-byte pieces of 16 rows per instruction and cost 25 us on a 32 MB output.
 #include "common.cuh"
 
+#include <mutex>
+
 namespace va {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -88,12 +90,13 @@ __device__ __forceinline__ i32x8 cat8(i32x4 lo, i32x4 hi) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <typename out_t, int BM, int BN, int WM, int WN, int NST, int KB, bool VEC_STORE>
+template <typename out_t, int BM, int BN, int WM, int WN, int NST, int KB, bool VEC_STORE,
+          bool SPLITK>
 __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
     out_t* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ a_scales, const float* __restrict__ b_scales,
     const out_t* __restrict__ bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-    int a_scale_numel, int b_scale_numel) {
+    int a_scale_numel, int b_scale_numel, float* ws, unsigned* ctr, int S) {
   constexpr int NW = WM * WN;
   constexpr int A_BYTES = BM * LBK, W_BYTES = BN * LBK, STAGE = A_BYTES + W_BYTES;
   constexpr int MT = BM / WM / 16, NT = BN / WN / 16;   // MFMA tiles per wave
@@ -117,8 +120,16 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
   const int nwg = tiles_m * tiles_n;
   int wg = blockIdx.x;
   {
-    const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+    // hardware workgroup i runs on XCD i % 8: give every XCD a contiguous run of virtual ids
+    // (split-K: of one K slice), so the tiles that share a weight panel share an L2
+    const int tot = SPLITK ? nwg * S : nwg;
+    const int q = tot / 8, r = tot % 8, xcd = wg % 8, idx = wg / 8;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int z = 0;   // K slice of this workgroup
+  if constexpr (SPLITK) {
+    z = wg / nwg;
+    wg -= z * nwg;
   }
   const int tm = wg % tiles_m, tn = wg / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -179,7 +190,14 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
   // in flight while group g is consumed, and group g+NST-1 is issued into the buffers group
   // g-1 just left.  (KB > 1 is for small tiles, where a barrier per block would leave the
   // latency chain barrier -> ds_read -> MFMA exposed once per 2..4 MFMAs.)
-  const int ng = K / (LBK * KB);   // host guarantees K % (128 KB) == 0
+  int ng = K / (LBK * KB);   // host guarantees K % (128 KB) == 0
+  if constexpr (SPLITK) {
+    // slice z takes groups [ng z / S, ng (z+1) / S): bump the (uniform) operand bases
+    const int g0 = (int)((int64_t)ng * z / S);
+    ng = (int)((int64_t)ng * (z + 1) / S) - g0;
+    a += (int64_t)g0 * (KB * LBK);
+    b += (int64_t)g0 * (KB * LBK);
+  }
   auto group_load = [&](int buf, int g) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) stage_load(buf * KB + kb, (g * KB + kb) * LBK);
@@ -251,6 +269,55 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
               wf[nt], af, acc[nt][mt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
       }
     });
+  }
+
+  if constexpr (SPLITK) {
+    // Split-K fix-up without a second kernel: every slice parks its fp32 accumulators in
+    // the workspace (one float per lane and store, consecutive lanes consecutive), then
+    // takes a ticket from the tile's counter; the workgroup that draws the last ticket adds
+    // the S partials IN SLICE ORDER (bit-identical whoever comes last), resets the counter for
+    // the next launch and runs the ordinary epilogue.  Nobody waits for anybody.
+    // The partials travel as device-scope relaxed atomics (sc1 stores / loads: coherent
+    // across the 8 XCD L2s by themselves).  A __threadfence() here instead writes back and
+    // invalidates the whole L2 per wave and made the kernel 10-50x slower.
+    constexpr int NTHR = 64 * NW;
+    constexpr int NACC = NT * MT * 4;   // floats per lane
+    float* part = ws + (size_t)wg * S * (NACC * NTHR) + tid;
+    {
+      float* mine = part + (size_t)z * (NACC * NTHR);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            __hip_atomic_store(mine + ((nt * MT + mt) * 4 + r) * NTHR, acc[nt][mt][r],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own partial has been written through
+    __syncthreads();   // everybody's has (and every wave is past its last read of `lds`)
+    volatile int* flag = reinterpret_cast<volatile int*>(lds);
+    if (tid == 0) {
+      const unsigned old =
+          __hip_atomic_fetch_add(ctr + wg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = old == (unsigned)(S - 1);
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+    if (tid == 0) __hip_atomic_store(ctr + wg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* p = part + ((nt * MT + mt) * 4 + r) * NTHR;
+          float v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int zz = 1; zz < S; ++zz)
+            v += __hip_atomic_load(p + (size_t)zz * (NACC * NTHR), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+          acc[nt][mt][r] = v;
+        }
   }
 
   // ---- epilogue: lane holds C^T[n = 16 nt + 4 g4 + r][m = 16 mt + c16] ---------------
@@ -346,35 +413,95 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
 struct GldsArgs {
   void* out; const void* a; const void* b; const float* a_scales; const float* b_scales;
   const void* bias; int M, N, K; int64_t lda, ldb, ldc; int asn, bsn; bool vec; hipStream_t st;
+  int splits;
 };
 
-template <typename out_t, int BM, int BN, int WM, int WN, int NST, int KB>
+// Split-K workspace, one per device: a ring of fp32 partials and a ring of ticket counters.
+// Every launch takes the next slice of both rings, so launches that overlap on different
+// streams work on different memory unless more than a ring's worth of them is in flight at
+// once (documented in DESIGN.md; "mm_splitk" = 1 turns splitting off).  Allocated on the
+// first split launch on the device -- never during stream capture: such a call runs
+// unsplit -- and kept until the process ends.  Counters reset themselves (kernel above).
+constexpr size_t SPLIT_WS_BYTES = (size_t)64 << 20;
+constexpr int SPLIT_WS_TILES = 16384;
+struct SplitWs { float* ws; unsigned* ctr; size_t cursor; int ctr_cursor; };
+static SplitWs g_split_ws[64];
+static std::mutex g_split_mu;
+
+static bool split_workspace(hipStream_t st, size_t bytes, int tiles, float** ws, unsigned** ctr) {
+  int dev = 0;
+  if (bytes > SPLIT_WS_BYTES || tiles > SPLIT_WS_TILES) return false;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  SplitWs& w = g_split_ws[dev];
+  if (!w.ws) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return false;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, SPLIT_WS_BYTES + SPLIT_WS_TILES * sizeof(unsigned)) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    if (hipMemset((char*)p + SPLIT_WS_BYTES, 0, SPLIT_WS_TILES * sizeof(unsigned)) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(p);
+      return false;
+    }
+    w = {(float*)p, (unsigned*)((char*)p + SPLIT_WS_BYTES), 0, 0};
+  }
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (w.cursor + bytes > SPLIT_WS_BYTES) w.cursor = 0;
+  if (w.ctr_cursor + tiles > SPLIT_WS_TILES) w.ctr_cursor = 0;
+  *ws = (float*)((char*)w.ws + w.cursor);
+  *ctr = w.ctr + w.ctr_cursor;
+  w.cursor += bytes;
+  w.ctr_cursor += tiles;
+  return true;
+}
+
+#define GLDS_LAUNCH(VEC, SPLIT, GRID, WS, CTR, S)                                                  \
+  hipLaunchKernelGGL((scaled_mm_glds_kernel<out_t, BM, BN, WM, WN, NST, KB, VEC, SPLIT>),          \
+                     dim3(GRID), dim3(64 * WM * WN), 0, g.st, (out_t*)g.out, (const uint8_t*)g.a,  \
+                     (const uint8_t*)g.b, g.a_scales, g.b_scales, (const out_t*)g.bias, g.M, g.N,  \
+                     g.K, g.lda, g.ldb, g.ldc, g.asn, g.bsn, WS, CTR, S)
+
+template <typename out_t, int BM, int BN, int WM, int WN, int NST, int KB, bool CAN_SPLIT>
 static void launch_glds_t(const GldsArgs& g) {
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  if (g.vec)
-    hipLaunchKernelGGL((scaled_mm_glds_kernel<out_t, BM, BN, WM, WN, NST, KB, true>), dim3(tiles),
-                       dim3(64 * WM * WN), 0, g.st, (out_t*)g.out, (const uint8_t*)g.a,
-                       (const uint8_t*)g.b, g.a_scales, g.b_scales, (const out_t*)g.bias, g.M, g.N,
-                       g.K, g.lda, g.ldb, g.ldc, g.asn, g.bsn);
-  else
-    hipLaunchKernelGGL((scaled_mm_glds_kernel<out_t, BM, BN, WM, WN, NST, KB, false>), dim3(tiles),
-                       dim3(64 * WM * WN), 0, g.st, (out_t*)g.out, (const uint8_t*)g.a,
-                       (const uint8_t*)g.b, g.a_scales, g.b_scales, (const out_t*)g.bias, g.M, g.N,
-                       g.K, g.lda, g.ldb, g.ldc, g.asn, g.bsn);
+  if constexpr (CAN_SPLIT) {
+    int S = g.splits;
+    const int ng = g.K / (LBK * KB);
+    if (S > ng) S = ng;
+    float* ws = nullptr;
+    unsigned* ctr = nullptr;
+    if (S > 1 && g.vec &&
+        split_workspace(g.st, (size_t)tiles * S * BM * BN * sizeof(float), tiles, &ws, &ctr)) {
+      GLDS_LAUNCH(true, true, tiles * S, ws, ctr, S);
+      return;
+    }
+  }
+  if (g.vec) GLDS_LAUNCH(true, false, tiles, nullptr, nullptr, 1);
+  else GLDS_LAUNCH(false, false, tiles, nullptr, nullptr, 1);
 }
+#undef GLDS_LAUNCH
 
 template <typename out_t>
 static void launch_glds_shape(int shape, const GldsArgs& g) {
   switch (shape) {
-    case 2: launch_glds_t<out_t, 256, 256, 2, 4, 2, 1>(g); break;
-    case 3: launch_glds_t<out_t, 128, 128, 2, 4, 2, 1>(g); break;
-    case 4: launch_glds_t<out_t, 128, 128, 2, 4, 2, 2>(g); break;
-    case 5: launch_glds_t<out_t, 128, 64, 4, 2, 3, 1>(g); break;
-    case 6: launch_glds_t<out_t, 128, 64, 4, 2, 3, 2>(g); break;
-    case 7: launch_glds_t<out_t, 64, 64, 2, 2, 4, 1>(g); break;
-    case 8: launch_glds_t<out_t, 64, 64, 2, 2, 2, 4>(g); break;
-    case 9: launch_glds_t<out_t, 64, 32, 2, 2, 4, 1>(g); break;
-    default: launch_glds_t<out_t, 64, 32, 2, 2, 3, 4>(g); break;   // 10
+    case 2: launch_glds_t<out_t, 256, 256, 2, 4, 2, 1, false>(g); break;
+    case 3: launch_glds_t<out_t, 128, 128, 2, 4, 2, 1, true>(g); break;
+    case 4: launch_glds_t<out_t, 128, 128, 2, 4, 2, 2, true>(g); break;
+    case 5: launch_glds_t<out_t, 128, 64, 4, 2, 3, 1, true>(g); break;
+    case 6: launch_glds_t<out_t, 128, 64, 4, 2, 3, 2, true>(g); break;
+    case 7: launch_glds_t<out_t, 64, 64, 2, 2, 4, 1, true>(g); break;
+    case 8: launch_glds_t<out_t, 64, 64, 2, 2, 2, 4, true>(g); break;
+    case 9: launch_glds_t<out_t, 64, 32, 2, 2, 4, 1, true>(g); break;
+    case 10: launch_glds_t<out_t, 64, 32, 2, 2, 3, 4, true>(g); break;
+    case 12: launch_glds_t<out_t, 32, 128, 1, 4, 4, 1, true>(g); break;
+    default: launch_glds_t<out_t, 32, 128, 1, 4, 3, 2, true>(g); break;   // 13
   }
 }
 
@@ -389,13 +516,14 @@ bool scaled_mm_large_fits(int M, int N, int K, int64_t lda, int64_t ldb) {
 void launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
                             const float* a_scales, const float* b_scales, const void* bias, int M,
                             int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int asn, int bsn,
-                            int out_dtype, bool vec, hipStream_t st) {
+                            int out_dtype, bool vec, int splits, hipStream_t st) {
   // shape = a GldsTile::id of the table in scaled_mm.hip.  Shapes that consume KB blocks per
   // barrier need K % (128 KB) == 0; otherwise the same tile with KB = 1.
-  static const int kb_of[11] = {1, 1, 1, 1, 2, 1, 2, 1, 4, 1, 4};
-  if (shape < 2 || shape > 10) shape = 3;
+  static const int kb_of[14] = {1, 1, 1, 1, 2, 1, 2, 1, 4, 1, 4, 1, 1, 2};
+  if (shape < 2 || shape > 13 || shape == 11) shape = 3;
   if (K % (LBK * kb_of[shape]) != 0) shape -= 1;
-  const GldsArgs g{out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc, asn, bsn, vec, st};
+  const GldsArgs g{out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc, asn, bsn, vec, st,
+                   splits};
   if (out_dtype == VLLM_AMD_BF16) launch_glds_shape<bf16_t>(shape, g);
   else launch_glds_shape<f16_t>(shape, g);
 }
