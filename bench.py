@@ -175,14 +175,24 @@ def run_cache_quant(device, iters=20):
     from vllm_amd import _custom_ops as ops
     out = {}
     # decode-step cache write at configs[1]: T=64 tokens ... plus a prefill-sized one
-    for name, T in (("decode_T64", 64), ("prefill_T8192", 8192)):
+    # (prefill: 4 sequences of T/4 consecutive slots over scattered blocks, starting 5 slots
+    # into a block as after a chunk boundary; "scattered": every token in a different block)
+    for name, T in (("decode_T64", 64), ("prefill_T8192", 8192), ("prefill_T32768", 32768),
+                    ("scattered_T8192", 8192)):
         KVH, D, BS = 8, 128, 16
         NB = max(T // BS * 2, 64)
         k = torch.randn((T, KVH, D), device=device, dtype=torch.bfloat16)
         v = torch.randn_like(k)
         kc = torch.zeros((NB, KVH, D // 16, BS, 16), dtype=torch.uint8, device=device)
         vc = torch.zeros((NB, KVH, D, BS), dtype=torch.uint8, device=device)
-        slots = torch.randperm(NB * BS, device=device)[:T].to(torch.int64)
+        if name.startswith("prefill"):
+            t = torch.arange(T, device=device)
+            seq, pos = t // (T // 4), t % (T // 4) + 5
+            per_seq = (T // 4 + 5 + BS - 1) // BS
+            perm = torch.randperm(NB, device=device)
+            slots = (perm[seq * per_seq + pos // BS] * BS + pos % BS).to(torch.int64)
+        else:
+            slots = torch.randperm(NB * BS, device=device)[:T].to(torch.int64)
         sc = torch.tensor([0.05], device=device)
         fn = lambda: ops.reshape_and_cache(k, v, kc, vc, slots, "fp8", sc, sc)
         t = time_gpu_graph(fn, iters)

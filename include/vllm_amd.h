@@ -302,6 +302,7 @@ int vllm_amd_context_attention_fwd(
 /*                 take 2 or 4 K blocks per barrier; scaled_mm_large.hip),      */
 /*                 11 = weight-streaming kernel (M <= 32 only),                 */
 /*                 12, 13 = 32x128 tile (1 / 2 K blocks per barrier)            */
+/*   "cache_runs": 0 = reshape_and_cache always per token (no run detection)    */
 /*   "mm_splitk":  K slices per output tile of the direct-to-LDS kernels        */
 /*                 (0 = heuristic, 1 = never split, n = n slices; reduced       */
 /*                 inside the kernel through a per-device fp32 workspace)       */

@@ -48,6 +48,61 @@ def test_reshape_and_cache(ops, oracle, dtype, kv, D, BS):
     assert torch.equal(vc_d.cpu().view(torch.uint8), vc_o.view(torch.uint8))
 
 
+def _prefill_slots(T, NB, BS, seed):
+    """Slot mapping of a mixed batch: runs of consecutive slots that start and end anywhere
+    in a block (chunked prefill), a stretch of scattered decode slots, padding (-1)."""
+    g = torch.Generator().manual_seed(seed)
+    blocks = torch.randperm(NB, generator=g).tolist()
+    slots, bi = [], 0
+    starts = [0, 5, 16, 9, 31, 1, 0, 13]
+    lens = [64, 37, 16, 50, 7, 100, 3, 29]
+    i = 0
+    while len(slots) < T:
+        start, ln = starts[i % 8] % BS, lens[i % 8] + (i // 8)
+        i += 1
+        if i % 5 == 4:   # decode-like: scattered single slots and padding
+            for j in range(ln // 4):
+                slots.append(-1 if j % 6 == 5 else blocks[bi] * BS + (j * 7) % BS)
+                bi += 1
+            continue
+        pos = start
+        for _ in range(ln):   # one sequence: consecutive offsets, next block when one is full
+            slots.append(blocks[bi] * BS + pos)
+            pos += 1
+            if pos == BS:
+                pos, bi = 0, bi + 1
+        bi += 1
+    return torch.tensor(slots[:T], dtype=torch.int64)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("D,BS,T", [(128, 16, 1000), (128, 32, 517), (64, 16, 333), (256, 16, 260),
+                                    (80, 16, 300), (112, 32, 256)])
+def test_reshape_and_cache_prefill_runs(ops, oracle, dtype, kv, D, BS, T):
+    """num_tokens >= 256 takes the run-aware kernel (LDS-transposed V rows); the slot mapping
+    mixes every case it distinguishes.  Also checks that nothing outside the slots is touched."""
+    if kv != "auto" and D % 16:
+        pytest.skip("fp8 cache needs head_size % 16 == 0 (x = 16), as in the reference tests")
+    H, NB = 4, 400
+    key, value = _kv_inputs(T, H, D, dtype, D + BS + T, strided=(D == 128))
+    x = x_of(dtype, kv)
+    cdt = dtype if kv == "auto" else torch.uint8
+    slots = _prefill_slots(T, NB, BS, T)
+    ks = (key.float().abs().max() / 64.0).item() if kv != "auto" else 1.0
+    vs = (value.float().abs().max() / 64.0).item() if kv != "auto" else 1.0
+    g = torch.Generator().manual_seed(9)
+    kc0 = torch.randint(0, 120, (NB, H, D // x, BS, x), generator=g).to(cdt)
+    vc0 = torch.randint(0, 120, (NB, H, D, BS), generator=g).to(cdt)
+    kc_o, vc_o = kc0.clone(), vc0.clone()
+    oracle.reshape_and_cache(key, value, kc_o, vc_o, slots, kv, ks, vs)
+    kc_d, vc_d = kc0.cuda(), vc0.cuda()
+    ops.reshape_and_cache(key.cuda(), value.cuda(), kc_d, vc_d, slots.cuda(), kv,
+                          torch.tensor([ks], device="cuda"), torch.tensor([vs], device="cuda"))
+    assert torch.equal(kc_d.cpu().view(torch.uint8), kc_o.view(torch.uint8))
+    assert torch.equal(vc_d.cpu().view(torch.uint8), vc_o.view(torch.uint8))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kv", ["auto", "fp8"])
 @pytest.mark.parametrize("layout", ["NHD", "HND"])

@@ -64,6 +64,161 @@ __global__ void reshape_and_cache_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// reshape_and_cache for many tokens: one workgroup per (16 consecutive tokens, head).
+// Prefill and chunked prefill hand over runs of consecutive slots; for such a group the V
+// tile is transposed through LDS and every V row [d][16 tokens] leaves as ONE 16-byte
+// (fp8) store instead of 16 single-byte stores, and the K vectors of consecutive tokens
+// are contiguous 256-byte pieces.  A run may start anywhere in a block (chunk boundaries
+// do): the LDS columns keep the slots' alignment mod 16, partial 16-slot groups are
+// written as 4-byte units and single elements.  A group whose slots are not consecutive
+// (decode batches, padding slots < 0) takes the per-token scatter inside the same kernel.
+// Requires block_size % 16 == 0 and head_size <= 256.
+// ---------------------------------------------------------------------------
+template <typename scalar_t, typename cache_t, bool FP8>
+__global__ __launch_bounds__(256) void reshape_and_cache_runs_kernel(
+    const scalar_t* __restrict__ key, const scalar_t* __restrict__ value,
+    cache_t* __restrict__ key_cache, cache_t* __restrict__ value_cache,
+    const int64_t* __restrict__ slot_mapping, int64_t key_stride, int64_t value_stride,
+    int num_tokens, int num_heads, int head_size, int block_size, int hpw,
+    const float* __restrict__ k_scale_p, const float* __restrict__ v_scale_p) {
+  constexpr int CS = sizeof(cache_t);
+  constexpr int X = 16 / CS;    // elements of one K cache vector
+  constexpr int G = 16;         // tokens per workgroup
+  constexpr int U = 4 / CS;     // elements of a 4-byte unit
+  constexpr int W = 512;        // head elements (hpw * head_size <= W) per workgroup
+  constexpr int KI = W / X * G / 256, VI = W / 8 * G / 256, RI = W / 256;   // items per thread
+  __shared__ int64_t s_slot[G];
+  __shared__ __attribute__((aligned(16))) cache_t vt[G][W + X];   // [token][head, d], padded rows
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * G, h0 = blockIdx.y * hpw;
+  const int n = num_tokens - t0 < G ? num_tokens - t0 : G;
+  const int nh = num_heads - h0 < hpw ? num_heads - h0 : hpw;
+  const int width = nh * head_size;   // contiguous source elements per token
+  if (tid < G) s_slot[tid] = tid < n ? slot_mapping[t0 + tid] : -1;
+
+  // every load of the workgroup is issued before the first use (rows past n: token 0)
+  const scalar_t* kbase = key + (int64_t)t0 * key_stride + h0 * head_size;
+  const scalar_t* vbase = value + (int64_t)t0 * value_stride + h0 * head_size;
+  const int cpt = width / X;          // K chunks per token
+  Vec<scalar_t, X> kreg[KI];
+#pragma unroll
+  for (int u = 0; u < KI; ++u) {      // item = (chunk, token), token fastest
+    const int it = tid + 256 * u;
+    const int i = it % G, c = it / G;
+    const bool ok = c < cpt && i < n;
+    kreg[u] = *reinterpret_cast<const Vec<scalar_t, X>*>(kbase + (ok ? (int64_t)i * key_stride + c * X : 0));
+  }
+  const int cpv = width / 8;          // V chunks of 8 per token
+  Vec<scalar_t, 8> vreg[VI];
+#pragma unroll
+  for (int u = 0; u < VI; ++u) {      // item = (token, chunk), chunk fastest
+    const int it = tid + 256 * u;
+    const int i = it / cpv, c = it % cpv;
+    const bool ok = i < n;
+    vreg[u] = *reinterpret_cast<const Vec<scalar_t, 8>*>(vbase + (ok ? (int64_t)i * value_stride + c * 8 : 0));
+  }
+  float ks = 1.f, vs = 1.f;
+  if constexpr (FP8) { ks = *k_scale_p; vs = *v_scale_p; }
+  __syncthreads();
+
+  // a "run": consecutive slots up to the next multiple of 16 (segment A), then consecutive
+  // slots from a multiple of 16 (segment B: the sequence's next block, anywhere in the cache)
+  const int64_t slot0 = s_slot[0];
+  const int colbase = slot0 >= 0 ? (int)(slot0 % 16) : 0;
+  const int nA = n < 16 - colbase ? n : 16 - colbase;
+  const int64_t slotB = nA < n ? s_slot[nA] : 0;
+  bool run = slot0 >= 0 && slotB >= 0 && slotB % 16 == 0;
+  for (int i = 1; i < nA; ++i) run = run && s_slot[i] == slot0 + i;
+  for (int i = nA + 1; i < n; ++i) run = run && s_slot[i] == slotB + (i - nA);
+  auto conv = [](scalar_t v, float sc) -> cache_t {
+    if constexpr (FP8) return f32_to_fp8(kv_quant_prep(v, sc));
+    else return v;
+  };
+  const int64_t blk_elems = (int64_t)num_heads * head_size * block_size;
+  const int64_t head_off = (int64_t)h0 * head_size * block_size;
+
+  // K: a wave writes 256-byte pieces of a run (16 tokens x one 16-byte vector)
+  const int cph = head_size / X;
+#pragma unroll
+  for (int u = 0; u < KI; ++u) {
+    const int it = tid + 256 * u;
+    const int i = it % G, c = it / G;
+    const int64_t slot = s_slot[i];
+    if (c >= cpt || slot < 0) continue;   // slot < 0 also covers i >= n
+    const int64_t blk = slot / block_size, off = slot % block_size;
+    Vec<cache_t, X> kq;
+#pragma unroll
+    for (int j = 0; j < X; ++j) kq.v[j] = conv(kreg[u].v[j], ks);
+    const int hl = c / cph, xc = c % cph;
+    *reinterpret_cast<Vec<cache_t, X>*>(key_cache + blk * blk_elems + head_off +
+                                         ((int64_t)hl * head_size * block_size) +
+                                         ((int64_t)xc * block_size + off) * X) = kq;
+  }
+
+  // V: into the LDS tile (run) or scattered (anything else)
+#pragma unroll
+  for (int u = 0; u < VI; ++u) {
+    const int it = tid + 256 * u;
+    const int i = it / cpv, c = it % cpv;
+    if (i >= G) continue;
+    const int64_t slot = s_slot[i];
+    if (slot < 0) continue;
+    Vec<cache_t, 8> vq;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vq.v[j] = conv(vreg[u].v[j], vs);
+    if (run) {
+      *reinterpret_cast<Vec<cache_t, 8>*>(&vt[i][c * 8]) = vq;
+    } else {
+      const int64_t blk = slot / block_size, off = slot % block_size;
+      cache_t* dst = value_cache + blk * blk_elems + head_off + (int64_t)(c * 8) * block_size + off;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[(int64_t)j * block_size] = vq.v[j];
+    }
+  }
+  if (!run) return;
+  __syncthreads();
+
+  // rows of the transposed tile: column q = (slot0 % 16) + token keeps the slots' alignment,
+  // so columns [0,16) (segment A) and [16,32) (segment B) are 16-slot groups inside a block
+#pragma unroll
+  for (int u = 0; u < RI; ++u) {
+    const int d = tid + 256 * u;   // (head, d) row: rows of consecutive heads are contiguous
+    if (d >= width) continue;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int q0 = 16 * hh;
+      const int lo = colbase - q0 > 0 ? colbase - q0 : 0;
+      const int hi = colbase + n - q0 < 16 ? colbase + n - q0 : 16;
+      if (hi <= lo) continue;   // uniform
+      const int64_t sbase = hh == 0 ? slot0 - colbase : slotB;   // first slot of the 16-slot group
+      const int64_t blk = sbase / block_size, off = sbase % block_size;
+      cache_t* dst = value_cache + blk * blk_elems + head_off + (int64_t)d * block_size + off;
+      struct alignas(16) Row { cache_t e[16]; } row;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const int i = q0 + p - colbase;
+        row.e[p] = (p >= lo && p < hi) ? vt[i][d] : cache_t{};
+      }
+      if (lo == 0 && hi == 16) {
+        *reinterpret_cast<Row*>(dst) = row;
+      } else {
+#pragma unroll
+        for (int uu = 0; uu < 16 / U; ++uu) {
+          if (uu * U >= lo && uu * U + U <= hi) {
+            *reinterpret_cast<Vec<cache_t, U>*>(dst + uu * U) =
+                *reinterpret_cast<const Vec<cache_t, U>*>(&row.e[uu * U]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+              if (uu * U + j >= lo && uu * U + j < hi) dst[uu * U + j] = row.e[uu * U + j];
+          }
+        }
+      }
+    }
+  }
+}
+
 // Scalar fallback for layouts / alignments the vector kernel does not cover
 // (odd x, misaligned rows).  Same mapping as the reference element loop.
 template <typename scalar_t, typename cache_t, bool FP8>
@@ -187,6 +342,8 @@ __global__ void copy_blocks_kernel(uint8_t* __restrict__ kc, uint8_t* __restrict
 
 using namespace va;
 
+namespace va { int g_cache_runs = 1; }   // tuning "cache_runs": 0 = always the per-token kernel
+
 static inline bool aligned(const void* p, size_t a) { return (((uintptr_t)p) & (a - 1)) == 0; }
 
 template <typename scalar_t, bool FP8>
@@ -201,7 +358,20 @@ static int launch_reshape_and_cache(const void* key, const void* value, void* kc
                       (key_stride % x == 0) && (value_stride % x == 0) &&
                       aligned(key, sizeof(scalar_t) * XN) && aligned(value, sizeof(scalar_t) * XN) &&
                       aligned(kc, 16);
-  if (vec_ok) {
+  // many tokens: the run-aware kernel (16 tokens x 1 head per workgroup)
+  const bool runs_ok = vec_ok && sizeof(scalar_t) == 2 && num_tokens >= 256 && block_size % 16 == 0 &&
+                       head_size % 8 == 0 && head_size <= 256 && aligned(vc, 16);
+  if (runs_ok && g_cache_runs) {
+    int hpw = 512 / head_size;   // heads per workgroup: hpw * head_size <= 512 elements
+    if (hpw > num_heads) hpw = num_heads;
+    // fewer heads per workgroup while the launch would not fill the chip a few times over
+    while (hpw > 1 && (int64_t)((num_tokens + 15) / 16) * ((num_heads + hpw - 1) / hpw) < 4096) hpw /= 2;
+    hipLaunchKernelGGL((reshape_and_cache_runs_kernel<scalar_t, cache_t, FP8>),
+                       dim3((num_tokens + 15) / 16, (num_heads + hpw - 1) / hpw), dim3(256), 0, st,
+                       (const scalar_t*)key, (const scalar_t*)value, (cache_t*)kc, (cache_t*)vc,
+                       slot_mapping, key_stride, value_stride, num_tokens, num_heads, head_size,
+                       block_size, hpw, ks, vs);
+  } else if (vec_ok) {
     const int nchunks = num_heads * head_size / x;
     int threads = nchunks < 256 ? ((nchunks + 63) / 64) * 64 : 256;
     hipLaunchKernelGGL((reshape_and_cache_kernel<scalar_t, cache_t, FP8, XN>), dim3(num_tokens),
