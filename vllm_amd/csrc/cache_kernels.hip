@@ -31,8 +31,8 @@ __global__ void reshape_and_cache_kernel(
   const int64_t off = slot % block_size;
   const int chunks_per_head = head_size / X;
   const int nchunks = num_heads * chunks_per_head;
-  float ks = 1.f, vs = 1.f;
-  if constexpr (FP8) { ks = *k_scale_p; vs = *v_scale_p; }
+  Divisor ks(1.f), vs(1.f);
+  if constexpr (FP8) { ks = Divisor(*k_scale_p); vs = Divisor(*v_scale_p); }
 
   const scalar_t* krow = key + token * key_stride;
   const scalar_t* vrow = value + token * value_stride;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void reshape_and_cache_runs_kernel(
     const scalar_t* __restrict__ key, const scalar_t* __restrict__ value,
     cache_t* __restrict__ key_cache, cache_t* __restrict__ value_cache,
     const int64_t* __restrict__ slot_mapping, int64_t key_stride, int64_t value_stride,
-    int num_tokens, int num_heads, int head_size, int block_size, int hpw,
+    int num_tokens, int num_heads, int head_size, int block_size, int bs_log2, int hpw,
     const float* __restrict__ k_scale_p, const float* __restrict__ v_scale_p) {
   constexpr int CS = sizeof(cache_t);
   constexpr int X = 16 / CS;    // elements of one K cache vector
@@ -91,6 +91,12 @@ __global__ __launch_bounds__(256) void reshape_and_cache_runs_kernel(
   __shared__ int64_t s_slot[G];
   __shared__ __attribute__((aligned(16))) cache_t vt[G][W + X];   // [token][head, d], padded rows
   const int tid = threadIdx.x;
+  // slot -> (block, offset): a shift for the usual power-of-two block sizes (a 64-bit
+  // division per item otherwise)
+  auto split = [&](int64_t slot, int64_t& blk, int64_t& off) {
+    if (bs_log2 >= 0) { blk = slot >> bs_log2; off = slot & (block_size - 1); }
+    else { blk = slot / block_size; off = slot % block_size; }
+  };
   const int t0 = blockIdx.x * G, h0 = blockIdx.y * hpw;
   const int n = num_tokens - t0 < G ? num_tokens - t0 : G;
   const int nh = num_heads - h0 < hpw ? num_heads - h0 : hpw;
@@ -110,16 +116,22 @@ __global__ __launch_bounds__(256) void reshape_and_cache_runs_kernel(
     kreg[u] = *reinterpret_cast<const Vec<scalar_t, X>*>(kbase + (ok ? (int64_t)i * key_stride + c * X : 0));
   }
   const int cpv = width / 8;          // V chunks of 8 per token
+  const int cpv_log2 = (cpv & (cpv - 1)) == 0 ? 31 - __clz(cpv) : -1;
+  auto vitem = [&](int it, int& i, int& c) {   // item -> (token, chunk), chunk fastest
+    if (cpv_log2 >= 0) { i = it >> cpv_log2; c = it & (cpv - 1); }
+    else { i = it / cpv; c = it % cpv; }
+  };
   Vec<scalar_t, 8> vreg[VI];
 #pragma unroll
   for (int u = 0; u < VI; ++u) {      // item = (token, chunk), chunk fastest
     const int it = tid + 256 * u;
-    const int i = it / cpv, c = it % cpv;
+    int i, c;
+    vitem(it, i, c);
     const bool ok = i < n;
     vreg[u] = *reinterpret_cast<const Vec<scalar_t, 8>*>(vbase + (ok ? (int64_t)i * value_stride + c * 8 : 0));
   }
-  float ks = 1.f, vs = 1.f;
-  if constexpr (FP8) { ks = *k_scale_p; vs = *v_scale_p; }
+  Divisor ks(1.f), vs(1.f);
+  if constexpr (FP8) { ks = Divisor(*k_scale_p); vs = Divisor(*v_scale_p); }
   __syncthreads();
 
   // a "run": consecutive slots up to the next multiple of 16 (segment A), then consecutive
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(256) void reshape_and_cache_runs_kernel(
   bool run = slot0 >= 0 && slotB >= 0 && slotB % 16 == 0;
   for (int i = 1; i < nA; ++i) run = run && s_slot[i] == slot0 + i;
   for (int i = nA + 1; i < n; ++i) run = run && s_slot[i] == slotB + (i - nA);
-  auto conv = [](scalar_t v, float sc) -> cache_t {
+  auto conv = [](scalar_t v, Divisor sc) -> cache_t {
     if constexpr (FP8) return f32_to_fp8(kv_quant_prep(v, sc));
     else return v;
   };
@@ -146,7 +158,8 @@ __global__ __launch_bounds__(256) void reshape_and_cache_runs_kernel(
     const int i = it % G, c = it / G;
     const int64_t slot = s_slot[i];
     if (c >= cpt || slot < 0) continue;   // slot < 0 also covers i >= n
-    const int64_t blk = slot / block_size, off = slot % block_size;
+    int64_t blk, off;
+    split(slot, blk, off);
     Vec<cache_t, X> kq;
 #pragma unroll
     for (int j = 0; j < X; ++j) kq.v[j] = conv(kreg[u].v[j], ks);
@@ -160,7 +173,8 @@ __global__ __launch_bounds__(256) void reshape_and_cache_runs_kernel(
 #pragma unroll
   for (int u = 0; u < VI; ++u) {
     const int it = tid + 256 * u;
-    const int i = it / cpv, c = it % cpv;
+    int i, c;
+    vitem(it, i, c);
     if (i >= G) continue;
     const int64_t slot = s_slot[i];
     if (slot < 0) continue;
@@ -170,7 +184,8 @@ __global__ __launch_bounds__(256) void reshape_and_cache_runs_kernel(
     if (run) {
       *reinterpret_cast<Vec<cache_t, 8>*>(&vt[i][c * 8]) = vq;
     } else {
-      const int64_t blk = slot / block_size, off = slot % block_size;
+      int64_t blk, off;
+    split(slot, blk, off);
       cache_t* dst = value_cache + blk * blk_elems + head_off + (int64_t)(c * 8) * block_size + off;
 #pragma unroll
       for (int j = 0; j < 8; ++j) dst[(int64_t)j * block_size] = vq.v[j];
@@ -192,7 +207,8 @@ __global__ __launch_bounds__(256) void reshape_and_cache_runs_kernel(
       const int hi = colbase + n - q0 < 16 ? colbase + n - q0 : 16;
       if (hi <= lo) continue;   // uniform
       const int64_t sbase = hh == 0 ? slot0 - colbase : slotB;   // first slot of the 16-slot group
-      const int64_t blk = sbase / block_size, off = sbase % block_size;
+      int64_t blk, off;
+      split(sbase, blk, off);
       cache_t* dst = value_cache + blk * blk_elems + head_off + (int64_t)d * block_size + off;
       struct alignas(16) Row { cache_t e[16]; } row;
 #pragma unroll
@@ -233,8 +249,8 @@ __global__ void reshape_and_cache_scalar_kernel(
   if (slot < 0) return;
   const int64_t blk = slot / block_size;
   const int64_t off = slot % block_size;
-  float ks = 1.f, vs = 1.f;
-  if constexpr (FP8) { ks = *k_scale_p; vs = *v_scale_p; }
+  Divisor ks(1.f), vs(1.f);
+  if constexpr (FP8) { ks = Divisor(*k_scale_p); vs = Divisor(*v_scale_p); }
   const int n = num_heads * head_size;
   const int64_t blk_elems = (int64_t)n * block_size;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -272,8 +288,8 @@ __global__ void reshape_and_cache_flash_kernel(
   if (slot < 0) return;
   const int64_t blk = slot / block_size;
   const int64_t off = slot % block_size;
-  float ks = 1.f, vs = 1.f;
-  if constexpr (FP8) { ks = *k_scale_p; vs = *v_scale_p; }
+  Divisor ks(1.f), vs(1.f);
+  if constexpr (FP8) { ks = Divisor(*k_scale_p); vs = Divisor(*v_scale_p); }
   const int vec_per_head = head_size / VEC;
   const int nvec = num_heads * vec_per_head;
   const scalar_t* krow = key + token * key_stride;
@@ -308,10 +324,11 @@ template <typename scalar_t, bool TO_FP8>
 __global__ void convert_fp8_kernel(void* __restrict__ dst_, const void* __restrict__ src_,
                                    int64_t n, float scale) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const Divisor dv(scale);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     if constexpr (TO_FP8) {
       const scalar_t* src = (const scalar_t*)src_;
-      ((uint8_t*)dst_)[i] = f32_to_fp8(kv_quant_prep(src[i], scale));
+      ((uint8_t*)dst_)[i] = f32_to_fp8(kv_quant_prep(src[i], dv));
     } else {
       const uint8_t* src = (const uint8_t*)src_;
       ((scalar_t*)dst_)[i] = from_f32<scalar_t>(fp8_to_f32(src[i]) * scale);
@@ -362,6 +379,8 @@ static int launch_reshape_and_cache(const void* key, const void* value, void* kc
   const bool runs_ok = vec_ok && sizeof(scalar_t) == 2 && num_tokens >= 256 && block_size % 16 == 0 &&
                        head_size % 8 == 0 && head_size <= 256 && aligned(vc, 16);
   if (runs_ok && g_cache_runs) {
+    int bs_log2 = -1;
+    for (int i = 4; i < 16; ++i) if (block_size == (1 << i)) bs_log2 = i;
     int hpw = 512 / head_size;   // heads per workgroup: hpw * head_size <= 512 elements
     if (hpw > num_heads) hpw = num_heads;
     // fewer heads per workgroup while the launch would not fill the chip a few times over
@@ -370,7 +389,7 @@ static int launch_reshape_and_cache(const void* key, const void* value, void* kc
                        dim3((num_tokens + 15) / 16, (num_heads + hpw - 1) / hpw), dim3(256), 0, st,
                        (const scalar_t*)key, (const scalar_t*)value, (cache_t*)kc, (cache_t*)vc,
                        slot_mapping, key_stride, value_stride, num_tokens, num_heads, head_size,
-                       block_size, hpw, ks, vs);
+                       block_size, bs_log2, hpw, ks, vs);
   } else if (vec_ok) {
     const int nchunks = num_heads * head_size / x;
     int threads = nchunks < 256 ? ((nchunks + 63) / 64) * 64 : 256;

@@ -123,6 +123,10 @@ __global__ void per_token_quant_kernel(uint8_t* __restrict__ out, float* __restr
     tout[i] = f32_to_fp8(qscale<false>(to_f32(tin[i]), s));
 }
 
+// fused_quant.hip: whole rows in registers (hidden % 8 == 0, <= 16384, aligned)
+bool per_token_quant_rows(void* out, const void* in, float* scales, const float* scale_ub,
+                          int64_t num_tokens, int hidden, int dtype, hipStream_t st);
+
 }  // namespace va
 
 using namespace va;
@@ -208,6 +212,10 @@ extern "C" int vllm_amd_dynamic_per_token_scaled_fp8_quant(void* out, const void
   VA_REQUIRE(num_tokens < (1ll << 31), VLLM_AMD_EINVAL, "too many tokens");
   hipStream_t st = (hipStream_t)stream;
   if (hidden_size == 0) return VLLM_AMD_OK;
+  if (per_token_quant_rows(out, input, scales, scale_ub, num_tokens, hidden_size, dtype, st)) {
+    VA_LAUNCH_CHECK("dynamic_per_token_scaled_fp8_quant launch");
+    return VLLM_AMD_OK;
+  }
   if (dtype == VLLM_AMD_F32) launch_per_token<float>(out, input, scales, scale_ub, num_tokens, hidden_size, st);
   else if (dtype == VLLM_AMD_F16) launch_per_token<f16_t>(out, input, scales, scale_ub, num_tokens, hidden_size, st);
   else if (dtype == VLLM_AMD_BF16) launch_per_token<bf16_t>(out, input, scales, scale_ub, num_tokens, hidden_size, st);

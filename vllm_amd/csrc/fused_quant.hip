@@ -13,7 +13,6 @@ namespace va {
 
 constexpr float kQMax = 448.0f;
 constexpr int ROW_THREADS = 256;
-constexpr int MAX_CHUNKS = 4;   // 8-element chunks per thread held in registers: hidden <= 8192
 
 template <typename T> struct alignas(sizeof(T) * 8) Vec8 { T v[8]; };
 
@@ -46,7 +45,7 @@ __device__ __forceinline__ float norm_elem(float x, float rms, T w) {
 }
 __device__ __forceinline__ float clamp_q(float x) { return fmaxf(-kQMax, fminf(x, kQMax)); }
 
-enum { MODE_STATIC = 0, MODE_ADD_STATIC = 1, MODE_DYNAMIC = 2 };
+enum { MODE_STATIC = 0, MODE_ADD_STATIC = 1, MODE_DYNAMIC = 2, MODE_QUANT = 3 };
 
 // x of one element under the three residual conventions; updates the residual
 template <typename T, int MODE>
@@ -67,75 +66,117 @@ __device__ __forceinline__ float take_x(T in, T* res_slot, bool has_res) {
   return x;
 }
 
-// Row in registers: hidden % 8 == 0, hidden <= 8192, 16-byte aligned rows.
-template <typename T, int MODE>
+// Row in registers: hidden % 8 == 0, 16-byte aligned rows.  A row belongs to W waves (1 for
+// hidden <= 2048: reductions never leave the wave, no barrier, 4 rows per workgroup); a lane
+// holds CH chunks of 8 elements and issues all its loads before the first use.
+// MODE_QUANT is dynamic_per_token_scaled_fp8_quant (no norm, no weight).
+template <typename T, int MODE, int W, int CH>
 __global__ __launch_bounds__(ROW_THREADS) void row_quant_vec_kernel(
     uint8_t* __restrict__ out, const T* __restrict__ in, int64_t in_stride, T* __restrict__ residual,
     const T* __restrict__ weight, const float* __restrict__ scale_p, float* __restrict__ scales,
-    const float* __restrict__ scale_ub, float eps, int hidden) {
-  __shared__ float red[8];
-  const int64_t t = blockIdx.x;
+    const float* __restrict__ scale_ub, float eps, int hidden, int64_t num_tokens) {
+  constexpr int RPB = 4 / W;   // rows per workgroup
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = wave % W;
+  int64_t t = (int64_t)blockIdx.x * RPB + wave / W;
+  const bool live = t < num_tokens;   // spare waves redo the last row and store nothing
+  if (!live) t = num_tokens - 1;
   const int nchunk = hidden >> 3;
   const Vec8<T>* vin = reinterpret_cast<const Vec8<T>*>(in + t * in_stride);
   Vec8<T>* vres = residual ? reinterpret_cast<Vec8<T>*>(residual + t * hidden) : nullptr;
   const Vec8<T>* vw = reinterpret_cast<const Vec8<T>*>(weight);
   const bool has_res = residual != nullptr;
-
-  float x[MAX_CHUNKS][8];
-  float ss = 0.f;
+  auto row_sum = [&](float v, int k) {
+    v = wave_sum(v);
+    if constexpr (W > 1) {
+      red[k][wave] = v;
+      __syncthreads();
+      v = 0.f;
 #pragma unroll
-  for (int c = 0; c < MAX_CHUNKS; ++c) {
-    const int i = c * ROW_THREADS + threadIdx.x;
+      for (int i = 0; i < W; ++i) v += red[k][(wave / W) * W + i];
+    }
+    return v;
+  };
+  auto row_max = [&](float v, int k) {
+    v = wave_max(v);
+    if constexpr (W > 1) {
+      red[k][wave] = v;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < W; ++i) v = fmaxf(v, red[k][(wave / W) * W + i]);
+    }
+    return v;
+  };
+
+  Vec8<T> a[CH], r[CH], w[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int i = (c * W + sub) * 64 + lane;
     if (i < nchunk) {
-      const Vec8<T> a = vin[i];
-      Vec8<T> r;
-      if (MODE != MODE_STATIC && has_res) r = vres[i];
+      a[c] = vin[i];
+      if (MODE != MODE_STATIC && MODE != MODE_QUANT && has_res) r[c] = vres[i];
+      if constexpr (MODE != MODE_QUANT) w[c] = vw[i];
+    }
+  }
+  float x[CH][8];
+  float ss = 0.f, amax = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int i = (c * W + sub) * 64 + lane;
+    if (i < nchunk) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        x[c][j] = take_x<T, MODE>(a.v[j], &r.v[j], has_res);
-        ss += x[c][j] * x[c][j];
+        if constexpr (MODE == MODE_QUANT) {
+          x[c][j] = to_f32(a[c].v[j]);
+          amax = fmaxf(amax, fabsf(x[c][j]));
+        } else {
+          x[c][j] = take_x<T, MODE>(a[c].v[j], &r[c].v[j], has_res);
+          ss += x[c][j] * x[c][j];
+        }
       }
-      if (MODE != MODE_STATIC && has_res) vres[i] = r;
+      if (MODE != MODE_STATIC && MODE != MODE_QUANT && has_res && live) vres[i] = r[c];
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[c][j] = 0.f;
     }
   }
-  ss = block_sum(ss, red);
-  const float rms = rsqrtf(ss / (float)hidden + eps);
-
-  float amax = 0.f;
+  if constexpr (MODE != MODE_QUANT) {
+    ss = row_sum(ss, 0);
+    const float rms = rsqrtf(ss / (float)hidden + eps);
 #pragma unroll
-  for (int c = 0; c < MAX_CHUNKS; ++c) {
-    const int i = c * ROW_THREADS + threadIdx.x;
-    if (i < nchunk) {
-      const Vec8<T> w = vw[i];
+    for (int c = 0; c < CH; ++c) {
+      const int i = (c * W + sub) * 64 + lane;
+      if (i < nchunk) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        x[c][j] = norm_elem<T>(x[c][j], rms, w.v[j]);
-        amax = fmaxf(amax, fabsf(x[c][j]));
+        for (int j = 0; j < 8; ++j) {
+          x[c][j] = norm_elem<T>(x[c][j], rms, w[c].v[j]);
+          amax = fmaxf(amax, fabsf(x[c][j]));
+        }
       }
     }
   }
-  float s;
-  if constexpr (MODE == MODE_DYNAMIC) {
-    amax = block_max2(amax, red);
-    // layernorm_utils.cuh:79-90
+  float s, y = 0.f;
+  if constexpr (MODE == MODE_DYNAMIC || MODE == MODE_QUANT) {
+    amax = row_max(amax, 1);
+    // layernorm_utils.cuh:79-90, fp8/common.cu:60-70
     s = scale_ub ? fminf(amax, *scale_ub) : amax;
     s = fmaxf(s / kQMax, 1.0f / (kQMax * 512.0f));
-    if (threadIdx.x == 0) scales[t] = s;
+    y = 1.0f / s;
+    if (lane == 0 && sub == 0 && live) scales[t] = s;
   } else {
     s = 1.0f / *scale_p;   // "invert scale to avoid division" (layernorm_quant_kernels.cu:50)
   }
+  if (!live) return;
   uint2* vout = reinterpret_cast<uint2*>(out + t * hidden);
 #pragma unroll
-  for (int c = 0; c < MAX_CHUNKS; ++c) {
-    const int i = c * ROW_THREADS + threadIdx.x;
+  for (int c = 0; c < CH; ++c) {
+    const int i = (c * W + sub) * 64 + lane;
     if (i < nchunk) {
       float q[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        q[j] = clamp_q(MODE == MODE_DYNAMIC ? x[c][j] / s : x[c][j] * s);
+        q[j] = (MODE == MODE_DYNAMIC || MODE == MODE_QUANT) ? div_clamp448(x[c][j], s, y)
+                                                            : clamp_q(x[c][j] * s);
       vout[i] = make_uint2(f32x4_to_fp8x4(q[0], q[1], q[2], q[3]),
                            f32x4_to_fp8x4(q[4], q[5], q[6], q[7]));
     }
@@ -194,30 +235,32 @@ __global__ __launch_bounds__(ROW_THREADS) void row_quant_generic_kernel(
 template <typename T>
 __device__ __forceinline__ float silu_mul(T x, T y) {
   const float xf = to_f32(x);
-  const T a = from_f32<T>(xf / (1.0f + expf(-xf)));
+  // the hardware exp2 / rcp (each ~1 ulp): the result is rounded to T right away, and the
+  // accurate expf + IEEE division made this HBM-bound op VALU-bound
+  const T a = from_f32<T>(xf * __builtin_amdgcn_rcpf(1.0f + __expf(-xf)));
   return to_f32(from_f32<T>(to_f32(a) * to_f32(y)));
 }
 
+// VEC: 8 elements per thread, no index division: workgroup = (token(s), 256 chunks); rows
+// shorter than 256 chunks share a workgroup (2^tpb_log2 tokens, power-of-two chunk pitch).
 template <typename T, bool VEC>
 __global__ __launch_bounds__(ROW_THREADS) void silu_mul_quant_kernel(
     uint8_t* __restrict__ out, const T* __restrict__ in, const float* __restrict__ scale_p,
-    int64_t num_tokens, int d) {
+    int64_t num_tokens, int d, int tpb_log2) {
   const float inv = 1.0f / *scale_p;
   if constexpr (VEC) {
     const int cpt = d >> 3;   // chunks per token
-    const int64_t total = num_tokens * cpt;
-    for (int64_t idx = (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * ROW_THREADS) {
-      const int64_t t = idx / cpt;
-      const int c = (int)(idx - t * cpt);
-      const Vec8<T> x = reinterpret_cast<const Vec8<T>*>(in + t * 2 * d)[c];
-      const Vec8<T> y = reinterpret_cast<const Vec8<T>*>(in + t * 2 * d + d)[c];
-      float q[8];
+    const int pitch_log2 = 8 - tpb_log2;
+    const int64_t t = ((int64_t)blockIdx.x << tpb_log2) + (threadIdx.x >> pitch_log2);
+    const int c = blockIdx.y * ROW_THREADS + (threadIdx.x & ((1 << pitch_log2) - 1));
+    if (t >= num_tokens || c >= cpt) return;
+    const Vec8<T> x = reinterpret_cast<const Vec8<T>*>(in + t * 2 * d)[c];
+    const Vec8<T> y = reinterpret_cast<const Vec8<T>*>(in + t * 2 * d + d)[c];
+    float q[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) q[j] = clamp_q(silu_mul<T>(x.v[j], y.v[j]) * inv);
-      reinterpret_cast<uint2*>(out + t * d)[c] =
-          make_uint2(f32x4_to_fp8x4(q[0], q[1], q[2], q[3]), f32x4_to_fp8x4(q[4], q[5], q[6], q[7]));
-    }
+    for (int j = 0; j < 8; ++j) q[j] = clamp_q(silu_mul<T>(x.v[j], y.v[j]) * inv);
+    reinterpret_cast<uint2*>(out + t * d)[c] =
+        make_uint2(f32x4_to_fp8x4(q[0], q[1], q[2], q[3]), f32x4_to_fp8x4(q[4], q[5], q[6], q[7]));
   } else {
     const int64_t total = num_tokens * d;
     for (int64_t idx = (int64_t)blockIdx.x * ROW_THREADS + threadIdx.x; idx < total;
@@ -248,23 +291,74 @@ using namespace va;
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+template <typename T, int MODE, int W, int CH>
+static void launch_row_vec(void* out, const void* in, int64_t in_stride, void* residual,
+                           const void* weight, const float* scale, float* scales,
+                           const float* scale_ub, float eps, int64_t num_tokens, int hidden,
+                           hipStream_t st) {
+  constexpr int RPB = 4 / W;
+  hipLaunchKernelGGL((row_quant_vec_kernel<T, MODE, W, CH>),
+                     dim3((unsigned)((num_tokens + RPB - 1) / RPB)), dim3(ROW_THREADS), 0, st,
+                     (uint8_t*)out, (const T*)in, in_stride, (T*)residual, (const T*)weight, scale,
+                     scales, scale_ub, eps, hidden, num_tokens);
+}
+
+// rows of up to 16384 elements stay in registers; false = not handled (caller's fallback)
+template <typename T, int MODE>
+static bool launch_row_regs(void* out, const void* in, int64_t in_stride, void* residual,
+                            const void* weight, const float* scale, float* scales,
+                            const float* scale_ub, float eps, int64_t num_tokens, int hidden,
+                            hipStream_t st) {
+  const bool vec = hidden % 8 == 0 && hidden <= 16384 && (in_stride * sizeof(T)) % 16 == 0 &&
+                   aligned16(in) && (weight == nullptr || aligned16(weight)) &&
+                   (residual == nullptr || aligned16(residual)) && (((uintptr_t)out) & 7) == 0;
+  if (!vec) return false;
+#define LR(W, CH) launch_row_vec<T, MODE, W, CH>(out, in, in_stride, residual, weight, scale, scales, \
+                                                 scale_ub, eps, num_tokens, hidden, st)
+  // at most 4 chunks per lane up to 8192 (8 chunks cost 230 VGPRs in the dynamic mode)
+  // few rows: one row per workgroup (shortest chain per row)
+  if (num_tokens <= 1024 && hidden <= 4096) LR(4, 2);
+  else if (num_tokens <= 1024 && hidden <= 8192) LR(4, 4);
+  else if (hidden <= 1024) LR(1, 2);
+  else if (hidden <= 2048) LR(1, 4);
+  else if (hidden <= 4096) LR(2, 4);
+  else if (hidden <= 8192) LR(4, 4);
+  else LR(4, 8);
+#undef LR
+  return true;
+}
+
 template <typename T, int MODE>
 static void launch_row(void* out, const void* in, int64_t in_stride, void* residual,
                        const void* weight, const float* scale, float* scales,
                        const float* scale_ub, float eps, int64_t num_tokens, int hidden,
                        hipStream_t st) {
-  const bool vec = hidden % 8 == 0 && hidden <= ROW_THREADS * 8 * MAX_CHUNKS &&
-                   (in_stride * sizeof(T)) % 16 == 0 && aligned16(in) && aligned16(weight) &&
-                   (residual == nullptr || aligned16(residual)) && (((uintptr_t)out) & 7) == 0;
-  if (vec)
-    hipLaunchKernelGGL((row_quant_vec_kernel<T, MODE>), dim3((unsigned)num_tokens),
-                       dim3(ROW_THREADS), 0, st, (uint8_t*)out, (const T*)in, in_stride,
-                       (T*)residual, (const T*)weight, scale, scales, scale_ub, eps, hidden);
-  else
+  if (!launch_row_regs<T, MODE>(out, in, in_stride, residual, weight, scale, scales, scale_ub, eps,
+                                num_tokens, hidden, st))
     hipLaunchKernelGGL((row_quant_generic_kernel<T, MODE>), dim3((unsigned)num_tokens),
                        dim3(ROW_THREADS), 0, st, (uint8_t*)out, (const T*)in, in_stride,
                        (T*)residual, (const T*)weight, scale, scales, scale_ub, eps, hidden);
 }
+
+namespace va {
+// dynamic_per_token_scaled_fp8_quant with the row in registers (fp8_quant.hip calls this
+// first and falls back to its strided kernel when it returns false)
+bool per_token_quant_rows(void* out, const void* in, float* scales, const float* scale_ub,
+                          int64_t num_tokens, int hidden, int dtype, hipStream_t st) {
+  switch (dtype) {
+    case VLLM_AMD_F32:
+      return launch_row_regs<float, MODE_QUANT>(out, in, hidden, nullptr, nullptr, nullptr, scales,
+                                                scale_ub, 0.f, num_tokens, hidden, st);
+    case VLLM_AMD_F16:
+      return launch_row_regs<f16_t, MODE_QUANT>(out, in, hidden, nullptr, nullptr, nullptr, scales,
+                                                scale_ub, 0.f, num_tokens, hidden, st);
+    case VLLM_AMD_BF16:
+      return launch_row_regs<bf16_t, MODE_QUANT>(out, in, hidden, nullptr, nullptr, nullptr, scales,
+                                                 scale_ub, 0.f, num_tokens, hidden, st);
+    default: return false;
+  }
+}
+}  // namespace va
 
 template <int MODE>
 static int row_entry(const char* op, void* out, const void* in, int64_t in_stride, void* residual,
@@ -336,13 +430,22 @@ extern "C" int vllm_amd_silu_and_mul_quant(void* out, const void* input, const f
   VA_REQUIRE(dtype == VLLM_AMD_F16 || dtype == VLLM_AMD_BF16, VLLM_AMD_EUNSUPPORTED,
              "%s: input must be float16 or bfloat16", op);
   const bool vec = d % 8 == 0 && aligned16(input) && (((uintptr_t)out) & 7) == 0;
-  const int64_t work = vec ? num_tokens * (d >> 3) : num_tokens * d;
-  int64_t blocks = (work + ROW_THREADS - 1) / ROW_THREADS;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  dim3 grid;
+  int tpb_log2 = 0;
+  if (vec) {
+    const int cpt = d >> 3;
+    while (tpb_log2 < 8 && (cpt << (tpb_log2 + 1)) <= ROW_THREADS) ++tpb_log2;   // tokens per workgroup
+    grid = dim3((unsigned)((num_tokens + (1 << tpb_log2) - 1) >> tpb_log2),
+                (unsigned)((cpt + ROW_THREADS - 1) / ROW_THREADS));
+  } else {
+    int64_t blocks = (num_tokens * d + ROW_THREADS - 1) / ROW_THREADS;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    grid = dim3((unsigned)blocks);
+  }
   hipStream_t st = (hipStream_t)stream;
 #define SM(T, V)                                                                          \
-  hipLaunchKernelGGL((silu_mul_quant_kernel<T, V>), dim3((unsigned)blocks), dim3(ROW_THREADS), \
-                     0, st, (uint8_t*)out, (const T*)input, scale, num_tokens, d)
+  hipLaunchKernelGGL((silu_mul_quant_kernel<T, V>), grid, dim3(ROW_THREADS),               \
+                     0, st, (uint8_t*)out, (const T*)input, scale, num_tokens, d, tpb_log2)
   if (dtype == VLLM_AMD_F16) { if (vec) SM(f16_t, true); else SM(f16_t, false); }
   else { if (vec) SM(bf16_t, true); else SM(bf16_t, false); }
 #undef SM
