@@ -228,7 +228,14 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
 
   // ---- registers -> LDS (K tile [tok][D], V^T tile [d][tok], both chunk-swizzled) ----------------
   auto k_slot = [&](int tok, int c) { return lds_k + tok * KROW + ((c ^ (tok & KSWZ)) << 4); };
-  auto v_slot = [&](int d, int tc) { return lds_v + d * VROW + ((tc ^ ((d >> 1) & 7)) << 4); };
+  // V^T row d, tokens in the order the PV MFMA consumes them: 16-byte chunk q = 4 (tile / 2) + g
+  // holds tokens 4 g .. 4 g + 3 of the 16-token tiles 2 (tile / 2) and 2 (tile / 2) + 1 (8 bytes
+  // each), so that a lane's whole A fragment is ONE ds_read_b128 (two ds_read_b64 merged into a
+  // ds_read2 run at half the LDS rate).  v_quad = address of the 8 bytes of tokens n .. n + 3.
+  auto v_quad = [&](int d, int n) {
+    const int tt = n >> 4, g = (n >> 2) & 3;
+    return lds_v + d * VROW + ((((tt >> 1) * 4 + g) ^ ((d >> 1) & 7)) << 4) + (tt & 1) * 8;
+  };
   // new tokens' V stays row-major [tok][D] (a plain copy like K) and is consumed with the
   // transposing LDS read; chunk pairs (one 16-wide d tile) are swizzled by the token
   constexpr int VNSWZ = (KCH % 16 == 0) ? 7 : (KCH % 8 == 0) ? 3 : 1;   // stays inside the row
@@ -249,8 +256,12 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
           const int j = item % CPP, d = (item / CPP) % D, pg = item / (CPP * D);
           // stale cache bytes of tokens >= ctx may be NaN, and 0 * NaN = NaN in the PV product
           const int n = t * PF_BN + pg * BS + 8 * j;
-          if (item < V16_TOTAL)
-            *reinterpret_cast<uint4*>(v_slot(d, pg * CPP + j)) = mask_halfs(as_u4(vst[i]), d < dr ? ctx - n : 0);
+          if (item < V16_TOTAL) {
+            const uint4 v = mask_halfs(as_u4(vst[i]), d < dr ? ctx - n : 0);
+            const int nl = pg * BS + 8 * j;
+            *reinterpret_cast<uint2*>(v_quad(d, nl)) = make_uint2(v.x, v.y);
+            *reinterpret_cast<uint2*>(v_quad(d, nl + 4)) = make_uint2(v.z, v.w);
+          }
         });
       } else {
         static_for<K8_ITEMS>([&](auto ic_) {
@@ -269,13 +280,15 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
           const int item = tid + PF_THREADS * i;
           constexpr int CPP = BS / 16;
           const int j = item % CPP, d = (item / CPP) % D, pg = item / (CPP * D);
-          const int tc = (pg * BS + 16 * j) >> 3;
+          const int nl = pg * BS + 16 * j;
           if (item < 4 * D) {
-            const uint4 raw = mask_bytes(as_u4(vst[i]), d < dr ? ctx - (t * PF_BN + pg * BS + 16 * j) : 0);
+            const uint4 raw = mask_bytes(as_u4(vst[i]), d < dr ? ctx - (t * PF_BN + nl) : 0);
             uint4 lo, hi;   // exact widening; v_scale is applied to the probabilities
             widen16<T>(raw, lo, hi);
-            *reinterpret_cast<uint4*>(v_slot(d, tc)) = lo;
-            *reinterpret_cast<uint4*>(v_slot(d, tc + 1)) = hi;
+            *reinterpret_cast<uint2*>(v_quad(d, nl)) = make_uint2(lo.x, lo.y);
+            *reinterpret_cast<uint2*>(v_quad(d, nl + 4)) = make_uint2(lo.z, lo.w);
+            *reinterpret_cast<uint2*>(v_quad(d, nl + 8)) = make_uint2(hi.x, hi.y);
+            *reinterpret_cast<uint2*>(v_quad(d, nl + 12)) = make_uint2(hi.z, hi.w);
           }
         });
       }
@@ -299,9 +312,9 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   const uint8_t* k_frag[QK_STEPS];
 #pragma unroll
   for (int ks = 0; ks < QK_STEPS; ++ks) k_frag[ks] = k_slot(c16, 4 * ks + g4);
-  const uint8_t* v_frag[4];
+  const uint8_t* v_frag[2];   // per contraction step: tokens 4 g4 .. + 3 of tiles 2 ks2, 2 ks2 + 1
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt) v_frag[tt] = v_slot(c16, 2 * tt + (g4 >> 1)) + (g4 & 1) * 8;
+  for (int ks2 = 0; ks2 < 2; ++ks2) v_frag[ks2] = v_quad(c16, 32 * ks2 + 4 * g4);
   const uint8_t* vn_frag[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
@@ -405,9 +418,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
       if (is_ctx) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const uint2 va = *reinterpret_cast<const uint2*>(v_frag[ta] + 16 * dt * VROW);
-          const uint2 vb = *reinterpret_cast<const uint2*>(v_frag[tb] + 16 * dt * VROW);
-          const uint4 vf = make_uint4(va.x, va.y, vb.x, vb.y);
+          const uint4 vf = *reinterpret_cast<const uint4*>(v_frag[ks2] + 16 * dt * VROW);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) o[dt][mt] = Mma<T>::mfma(vf, pb[mt], o[dt][mt]);
         }
