@@ -107,6 +107,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   const float sc2 = p.sm_scale * kLog2e;
   float kscale = 1.f, vscale = 1.f;
   if constexpr (FP8) { kscale = *p.k_scale; vscale = *p.v_scale; }
+  const float vscale_log2 = log2f(vscale), vscale_inv = 1.0f / vscale;
 
   // ---- Q^T fragments: column m = c16 of the wave's tile mt, k = d = 32 ks + 8 g4 + j ------
   const int m_wave = start_m * PF_BM + 16 * MT * wave;
@@ -332,7 +333,9 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
     const bool is_ctx = t < ctx_tiles;
     const int n0 = is_ctx ? t * PF_BN : (t - ctx_tiles) * PF_BN;
     const float sct = (FP8 && is_ctx) ? sc2 * kscale : sc2;        // score scale of this tile
-    const float pv = (FP8 && is_ctx) ? vscale : 1.f;                // value scale of this tile
+    // value scale of this tile, as log2 and as reciprocal (1 for new tokens)
+    const float pv_log2 = (FP8 && is_ctx) ? vscale_log2 : 0.f;
+    const float pv_inv = (FP8 && is_ctx) ? vscale_inv : 1.f;
     f32x4 s[4][MT];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -388,19 +391,22 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
       const float m_use = m_new == -INFINITY ? 0.f : m_new;
       const float alpha = fast_exp2(m_run[mt] - m_use);
       m_run[mt] = m_new;
+      // v_scale rides in the exponent: exp2(s - (m - log2 v_scale)) = p * v_scale with no
+      // multiply per score; the row sum is taken of the scaled values and unscaled once
+      const float m_sub = FP8 ? m_use - pv_log2 : m_use;
       float psum = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         float e[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          e[r] = fast_exp2(s[nt][mt][r] - m_use);
+          e[r] = fast_exp2(s[nt][mt][r] - m_sub);
           psum += e[r];
-          if constexpr (FP8) e[r] *= pv;
         }
         pk[nt][mt][0] = Mma<T>::pack2(e[0], e[1]);   // p.to(v.dtype) (:216)
         pk[nt][mt][1] = Mma<T>::pack2(e[2], e[3]);
       }
+      if constexpr (FP8) psum *= pv_inv;
       l_run[mt] = l_run[mt] * alpha + psum;
       if (__any(alpha != 1.0f)) {
 #pragma unroll
