@@ -439,7 +439,7 @@ static int dispatch_mfma(const PagedAttnParams& p) {
 // partitions, one workgroup each.  A 128 KiB workgroup is all prologue and merge on this
 // chip (5.4 TB/s); the same kernel with ~1 MiB per workgroup streams at 6.4-6.5 TB/s
 // (profiles/r01_ab_attention.txt).  So a workgroup takes `sp` consecutive reference
-// partitions, chosen so the launch has ~512 workgroups (one round of 2 per CU), writes ONE
+// partitions (heuristic below), writes ONE
 // partial into the first of its scratch slots, and the reduce kernel visits every sp-th
 // slot.  The scratch tensors are caller-allocated temporaries of the reference's shape;
 // only the slots we read are written.
@@ -449,7 +449,15 @@ int paged_attention_mfma(const PagedAttnParams& p0) {
   if (p.partition_size > 0) {
     const int chunks = ceil_div(p.num_heads / p.num_kv_heads, 16);
     const int64_t total = (int64_t)p.num_seqs * p.num_kv_heads * chunks * p.max_num_partitions;
-    int64_t sp = (total + 511) / 512;   // one round of 2 workgroups per CU
+    // Uniform batches want one round of 2 workgroups per CU (512); real batches are ragged and
+    // a workgroup per (sequence, head) then waits for the longest sequence, so aim at ~2048
+    // workgroups -- the hardware hands them out as others finish -- but keep >= 2048 tokens per
+    // workgroup while that still fills one round (tools/bench_decode_grid.py: ragged 64 x
+    // [2k, 16k] tokens 244 -> 216 us, uniform 64 x 16k 339 -> 344 us).
+    const int64_t sp_fill = (total + 511) / 512, sp_bal = (total + 2047) / 2048;
+    const int64_t sp_min = p.partition_size >= 2048 ? 1 : 2048 / p.partition_size;
+    int64_t sp = sp_fill < sp_min ? sp_fill : sp_min;
+    if (sp < sp_bal) sp = sp_bal;
     if (g_pa_sp > 0) sp = g_pa_sp;
     if (sp < 1) sp = 1;
     if (sp > p.max_num_partitions) sp = p.max_num_partitions;
