@@ -66,8 +66,9 @@ __device__ __forceinline__ float take_x(T in, T* res_slot, bool has_res) {
   return x;
 }
 
-// Row in registers: hidden % 8 == 0, 16-byte aligned rows.  A row belongs to W waves (1 for
-// hidden <= 2048: reductions never leave the wave, no barrier, 4 rows per workgroup); a lane
+// Row in registers: hidden % 8 == 0, 16-byte aligned rows.  A row belongs to W waves (4 from
+// 2048 elements up; shorter rows share a workgroup, and with W = 1 the reductions never leave
+// the wave); a lane
 // holds CH chunks of 8 elements and issues all its loads before the first use.
 // MODE_QUANT is dynamic_per_token_scaled_fp8_quant (no norm, no weight).
 template <typename T, int MODE, int W, int CH>
@@ -316,12 +317,12 @@ static bool launch_row_regs(void* out, const void* in, int64_t in_stride, void* 
 #define LR(W, CH) launch_row_vec<T, MODE, W, CH>(out, in, in_stride, residual, weight, scale, scales, \
                                                  scale_ub, eps, num_tokens, hidden, st)
   // at most 4 chunks per lane up to 8192 (8 chunks cost 230 VGPRs in the dynamic mode)
-  // few rows: one row per workgroup (shortest chain per row)
-  if (num_tokens <= 1024 && hidden <= 4096) LR(4, 2);
-  else if (num_tokens <= 1024 && hidden <= 8192) LR(4, 4);
-  else if (hidden <= 1024) LR(1, 2);
-  else if (hidden <= 2048) LR(1, 4);
-  else if (hidden <= 4096) LR(2, 4);
+  // as few chunks per lane as the row allows (registers -> occupancy: 4096-wide rows measured
+  // 1 wave x 8 chunks 19.4 us, 2 x 4 16.5, 4 x 2 15.9 for the dynamic mode, M = 4096)
+  if (hidden <= 512) LR(1, 1);
+  else if (hidden <= 1024) LR(2, 1);
+  else if (hidden <= 2048) LR(4, 1);
+  else if (hidden <= 4096) LR(4, 2);
   else if (hidden <= 8192) LR(4, 4);
   else LR(4, 8);
 #undef LR
