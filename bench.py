@@ -282,6 +282,19 @@ def run_prefill(device, iters=5):
         out[f"B{B}_q{ql}_ctx{cl}_fp8kv"] = dict(us=round(t * 1e6, 1),
                                                 tflops=round(flops / t / 1e12, 1),
                                                 frac_of_bf16_peak=round(flops / t / 2.5e15, 4))
+        # the same problem through unified_attention (everything in a flash-layout fp8 cache)
+        from vllm_amd.attention.ops import unified_attention
+        nbu = (ql + cl + BS - 1) // BS
+        kf = torch.randint(0, 120, (B * nbu, BS, KVH, D), device=device, dtype=torch.uint8)
+        vf = torch.randint(0, 120, (B * nbu, BS, KVH, D), device=device, dtype=torch.uint8)
+        bt = torch.randperm(B * nbu, device=device).to(torch.int32).view(B, nbu)
+        fn = lambda: unified_attention(q, kf, vf, o, start, ql, seql, ql + cl, D ** -0.5, True,
+                                       (-1, -1), bt, 0.0, None, sc, sc)
+        t = time_gpu_graph(fn, iters)
+        out[f"unified_B{B}_q{ql}_ctx{cl}_fp8kv"] = dict(us=round(t * 1e6, 1),
+                                                        tflops=round(flops / t / 1e12, 1),
+                                                        frac_of_bf16_peak=round(flops / t / 2.5e15, 4))
+        del kf, vf
     return out
 
 

@@ -289,6 +289,39 @@ int vllm_amd_context_attention_fwd(
     int64_t vc_block_stride, int64_t vc_head_stride, float sm_scale, int sliding_window,
     int skip_decode, int dtype, int kv_cache_dtype, void* stream);
 
+/* Replaces unified_attention (vllm/attention/ops/triton_unified_attention.py:588-700; Triton
+ * kernels kernel_unified_attention_2d :52-272 / _3d :276-586): the V1 engine's attention over
+ * the FLASH-layout cache.  For sequence b the query tokens q[cu_seqlens_q[b] :
+ * cu_seqlens_q[b+1]] sit at positions ctx .. seqused_k[b]-1 (ctx = seqused_k[b] - query_len);
+ * query m attends to the cached keys n <= ctx + m (causal; the new tokens are already in the
+ * cache), optionally inside a sliding window, with logit soft-capping and ALiBi:
+ *   S = softmax_scale * q.k;  S = softcap * tanh(S / softcap) if softcap > 0;
+ *   masked (-inf) where n > ctx + m or ctx + m - n >= sliding_window (if > 0);
+ *   S += alibi_slope[head] * (n - ctx);  out = softmax(S) . v  (:219-262)
+ *   q, out   [num_tokens, num_heads, head_size] (element strides per token / head)
+ *   k_cache, v_cache  [num_blocks, block_size, num_kv_heads, head_size] through element
+ *            strides of dims 0, 1, 2 (head dim contiguous), dtype of q or e4m3 bytes
+ *   block_table int32 [num_seqs, *] (row stride), cu_seqlens_q int32 [num_seqs+1],
+ *            seqused_k int32 [num_seqs]
+ *   k_descale, v_descale  float, element 0 is used (the kernel's tl.load(k_scale), :177, :191);
+ *            fp8 cache only: k = (fp8 -> f32 * k_descale).to(q dtype)
+ *   output_scale  float[1] or NULL: out is e4m3 bytes = clamp(acc / l / scale) (:254-256)
+ *   sliding_window = 1 + window_size[0] of the reference call (0 = none) (:655)
+ * Supported here: f16 / bf16 queries (no fp8 queries: q_descale is "not supported" in the
+ * reference either, :609), head_size a multiple of 8 (16 with an fp8 cache) up to 128,
+ * block_size 16 / 32.  Decode-only batches run through the same kernel (correct, but the
+ * paged_attention_* ops above are the fast decode path). */
+int vllm_amd_unified_attention(
+    void* out, const void* q, const void* k_cache, const void* v_cache,
+    const int* cu_seqlens_q, const int* seqused_k, const int* block_table,
+    const float* k_descale, const float* v_descale, const float* alibi_slopes,
+    const float* output_scale, int num_seqs, int num_heads, int num_kv_heads, int head_size,
+    int block_size, int max_seqlen_q, int64_t block_table_stride, int64_t q_stride_t,
+    int64_t q_stride_h, int64_t o_stride_t, int64_t o_stride_h, int64_t kc_stride_block,
+    int64_t kc_stride_slot, int64_t kc_stride_head, int64_t vc_stride_block,
+    int64_t vc_stride_slot, int64_t vc_stride_head, float softmax_scale, int sliding_window,
+    float softcap, int dtype, int kv_cache_dtype, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Tuning knobs (no counterpart in the reference): used by tools/ and bench   */
 /* scripts to A/B kernel variants inside one process.                          */

@@ -336,3 +336,64 @@ def context_attention_fwd(q, k, v, o, kv_cache_dtype, k_cache, v_cache, b_loc, b
         _i64(o.stride(1)), _i64(k_cache.stride(0)), _i64(k_cache.stride(1)),
         _i64(v_cache.stride(0)), _i64(v_cache.stride(1)), _f(sm_scale), int(sliding_window),
         int(bool(skip_decode)), DT[q.dtype], _kv(kv_cache_dtype))
+
+
+# vllm/attention/ops/triton_unified_attention.py:52-272 (kernel_unified_attention_2d), 588-700.
+# Plain torch fp32 on the CPU, one (sequence, head) at a time, in the kernel's order of
+# operations: K / V dequantised and rounded to the query dtype (:172-192), S = scale * q.k
+# (:205), softcap (:207-208, 25-30), causal / padding mask (:198, 210-211), sliding window
+# (:213-215), ALiBi bias slope * (key position - context_len) (:217-218), softmax, P rounded
+# to V's dtype (:246), acc / L (:250), fp8 output (:253-256).  Same maths as the reference
+# test's ref_paged_attn (tests/kernels/attention/test_triton_unified_attention.py:25-77).
+# PARITY UNPINNED against the Triton kernel itself (Triton is not runnable here): pinned
+# instead against the context_attention_fwd restatement above, which computes the same
+# function when the new tokens' K / V are both passed densely and present in the cache
+# (tests/test_oracle.py::test_unified_oracle_vs_prefix_oracle).
+def unified_attention(q, k, v, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_seqlen_k,
+                      softmax_scale, causal, window_size, block_table, softcap, q_descale,
+                      k_descale, v_descale, alibi_slopes=None, output_scale=None) -> None:
+    assert causal and q_descale is None
+    qd = q.dtype
+    block_size = v.shape[1]
+    nkv = k.shape[2]
+    H = q.shape[1]
+    g = H // nkv
+    win = 1 + int(window_size[0])
+    fp8 = k.dtype in (torch.uint8, torch.float8_e4m3fn)
+    for i in range(len(seqused_k)):
+        q0, q1 = int(cu_seqlens_q[i]), int(cu_seqlens_q[i + 1])
+        qlen, kvlen = q1 - q0, int(seqused_k[i])
+        if qlen == 0:
+            continue
+        ctx = kvlen - qlen
+        nblk = (kvlen + block_size - 1) // block_size
+        idx = block_table[i, :nblk].long()
+        kk = k[idx].reshape(-1, nkv, k.shape[3])[:kvlen]
+        vv = v[idx].reshape(-1, nkv, v.shape[3])[:kvlen]
+        if fp8:
+            kk = (kk.view(torch.float8_e4m3fn).float() * float(k_descale.flatten()[0])).to(qd)
+            vv = (vv.view(torch.float8_e4m3fn).float() * float(v_descale.flatten()[0])).to(qd)
+        kk, vv = kk.float(), vv.float()
+        qpos = ctx + torch.arange(qlen)[:, None]
+        kpos = torch.arange(kvlen)[None, :]
+        keep = kpos <= qpos
+        if win > 0:
+            keep &= (qpos - kpos) < win
+        for h in range(H):
+            S = softmax_scale * (q[q0:q1, h].float() @ kk[:, h // g].t())
+            if softcap and softcap > 0:
+                S = softcap * torch.tanh(S / softcap)
+            S = torch.where(keep, S, torch.tensor(float("-inf")))
+            if alibi_slopes is not None:
+                S = S + float(alibi_slopes[h]) * (kpos - ctx)
+            m = S.max(dim=1, keepdim=True).values
+            m = torch.where(m > float("-inf"), m, torch.zeros_like(m))
+            P = torch.exp(S - m)
+            L = P.sum(dim=1, keepdim=True)
+            L = torch.where(L > 0, L, torch.ones_like(L))
+            acc = (P.to(qd).float() @ vv[:, h // g]) / L
+            if output_scale is not None:
+                acc = (acc / float(output_scale.flatten()[0])).clamp(-448.0, 448.0)
+                out[q0:q1, h] = acc.to(torch.float8_e4m3fn).view(out.dtype)
+            else:
+                out[q0:q1, h] = acc.to(out.dtype)

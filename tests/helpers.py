@@ -156,3 +156,42 @@ def prefill_reference(c, sliding_window=0, alibi_slopes=None, sm_scale=None):
         sc = sc.masked_fill(~mask, float("-inf"))
         out[s:s + ql] = torch.einsum("hmn,nhd->mhd", sc.softmax(-1), vf)
     return out
+
+
+def make_unified_case(seq_lens, H, KVH, D, BS, dtype, fp8=False, seed=0, num_blocks=None,
+                      kv_scale=1.0):
+    """Inputs of unified_attention built like the reference test
+    (tests/kernels/attention/test_triton_unified_attention.py:108-160): seq_lens = [(query_len,
+    kv_len)], N(0,1) data, flash-layout caches [NB, BS, KVH, D].  Unlike the reference (random
+    cache everywhere, block table sampled with replacement) the block table holds distinct
+    blocks and every slot past a sequence's kv_len holds NaN / random bytes, so that reading
+    past the sequence shows up."""
+    g = torch.Generator().manual_seed(seed)
+    B = len(seq_lens)
+    qls, kvls = [a for a, _ in seq_lens], [b for _, b in seq_lens]
+    q = torch.randn((sum(qls), H, D), generator=g).to(dtype)
+    mb = max((n + BS - 1) // BS for n in kvls) + 1
+    NB = num_blocks or (B * mb + 5)
+    bt = torch.randperm(NB, generator=g)[: B * mb].view(B, mb).to(torch.int32)
+    if fp8:
+        kc = torch.randint(0, 256, (NB, BS, KVH, D), generator=g, dtype=torch.uint8)
+        vc = torch.randint(0, 256, (NB, BS, KVH, D), generator=g, dtype=torch.uint8)
+    else:
+        kc = torch.full((NB, BS, KVH, D), float("nan"), dtype=dtype)
+        vc = torch.full((NB, BS, KVH, D), float("nan"), dtype=dtype)
+    for b in range(B):
+        n = kvls[b]
+        kk = torch.randn((n, KVH, D), generator=g)
+        vv = torch.randn((n, KVH, D), generator=g)
+        if fp8:
+            kk = (kk / kv_scale).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+            vv = (vv / kv_scale).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+        else:
+            kk, vv = kk.to(dtype), vv.to(dtype)
+        for t in range(n):
+            kc[int(bt[b, t // BS]), t % BS] = kk[t]
+            vc[int(bt[b, t // BS]), t % BS] = vv[t]
+    cu = torch.tensor([0] + list(torch.tensor(qls).cumsum(0)), dtype=torch.int32)
+    return dict(q=q, k=kc, v=vc, block_table=bt, cu_seqlens_q=cu,
+                seqused_k=torch.tensor(kvls, dtype=torch.int32), max_seqlen_q=max(qls),
+                max_seqlen_k=max(kvls), scale=torch.tensor([kv_scale]))

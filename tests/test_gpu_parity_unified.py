@@ -1,0 +1,111 @@
+"""GPU parity: unified_attention (flash-layout cache, causal, window / softcap / ALiBi / fp8)
+vs the CPU oracle's restatement of the Triton kernel.  Shapes and tolerance follow the
+reference's tests/kernels/attention/test_triton_unified_attention.py:80-200 (atol 1.5e-2,
+rtol 1e-2 on N(0,1) data); head size 256 of that test is outside this kernel (<= 128)."""
+import pytest
+import torch
+
+from helpers import make_unified_case
+
+pytestmark = pytest.mark.gpu
+
+ATOL, RTOL = 1.5e-2, 1e-2
+
+
+def run(orc, c, dtype, window=None, softcap=0.0, alibi=None, out_scale=None, fp8=False, view=None):
+    from vllm_amd.attention.ops import unified_attention
+    ws = (window - 1, 0) if window is not None else (-1, -1)
+    D = c["q"].shape[2]
+    sm = D ** -0.5
+    odt = torch.uint8 if out_scale is not None else dtype
+    ref = torch.zeros(c["q"].shape, dtype=odt)
+    kd = c["scale"] if fp8 else None
+    orc.unified_attention(c["q"], c["k"], c["v"], ref, c["cu_seqlens_q"], c["max_seqlen_q"],
+                          c["seqused_k"], c["max_seqlen_k"], sm, True, ws, c["block_table"],
+                          softcap, None, kd, kd, alibi, out_scale)
+    kc, vc = c["k"].cuda(), c["v"].cuda()
+    if view is not None:
+        kc, vc = view(kc), view(vc)
+    out = torch.zeros(c["q"].shape, dtype=odt, device="cuda")
+    unified_attention(c["q"].cuda(), kc, vc, out, c["cu_seqlens_q"].cuda(), c["max_seqlen_q"],
+                      c["seqused_k"].cuda(), c["max_seqlen_k"], sm, True, ws,
+                      c["block_table"].cuda(), softcap, None,
+                      None if kd is None else kd.cuda(), None if kd is None else kd.cuda(),
+                      None if alibi is None else alibi.cuda(),
+                      None if out_scale is None else out_scale.cuda())
+    if out_scale is not None:
+        a = out.cpu().view(torch.float8_e4m3fn).float() * float(out_scale)
+        b = ref.view(torch.float8_e4m3fn).float() * float(out_scale)
+        torch.testing.assert_close(a, b, atol=8e-3 + ATOL, rtol=0.13)
+    else:
+        torch.testing.assert_close(out.cpu().float(), ref.float(), atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("seq_lens", [[(1, 1328), (5, 18), (129, 463)], [(1, 523), (1, 37), (1, 2011)]])
+@pytest.mark.parametrize("num_heads", [(4, 4), (8, 2), (16, 2)])
+@pytest.mark.parametrize("block_size", [16, 32])
+@pytest.mark.parametrize("sliding_window", [None, 256])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("soft_cap", [None, 10.0, 50.0])
+def test_unified_reference_grid(oracle, seq_lens, num_heads, block_size, sliding_window, dtype, soft_cap):
+    """The reference test's grid at head size 128."""
+    c = make_unified_case(seq_lens, num_heads[0], num_heads[1], 128, block_size, dtype,
+                          seed=len(seq_lens) + num_heads[0] + block_size)
+    run(oracle, c, dtype, window=sliding_window, softcap=soft_cap or 0.0)
+
+
+@pytest.mark.parametrize("seq_lens", [[(700, 700), (300, 1500), (64, 64), (1, 1)], [(257, 1000), (130, 131)]])
+@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("window", [None, 100])
+def test_unified_long_prefill(oracle, seq_lens, D, dtype, window):
+    """Several row blocks per sequence: interior, diagonal and skipped tiles, pure prefill
+    (ctx 0) and chunked prefill, window narrower than a row block."""
+    c = make_unified_case(seq_lens, 8, 2, D, 16, dtype, seed=D + len(seq_lens))
+    run(oracle, c, dtype, window=window)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("block_size", [16, 32])
+@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("soft_cap", [None, 30.0])
+def test_unified_fp8_cache(oracle, dtype, block_size, D, soft_cap):
+    c = make_unified_case([(200, 900), (1, 77), (33, 33)], 8, 2, D, block_size, dtype, fp8=True,
+                          seed=block_size + D, kv_scale=0.75)
+    run(oracle, c, dtype, softcap=soft_cap or 0.0, fp8=True)
+
+
+@pytest.mark.parametrize("D", [32, 80, 96, 120, 128])
+def test_unified_head_sizes(oracle, D):
+    c = make_unified_case([(90, 400), (17, 17)], 4, 2, D, 16, torch.bfloat16, seed=D)
+    run(oracle, c, torch.bfloat16)
+
+
+@pytest.mark.parametrize("window", [None, 64])
+def test_unified_alibi(oracle, window):
+    c = make_unified_case([(150, 600), (1, 300), (40, 41)], 8, 4, 128, 16, torch.float16, seed=5)
+    slopes = 2.0 ** -(torch.arange(8).float() * 0.5 + 1)
+    run(oracle, c, torch.float16, alibi=slopes, window=window)
+
+
+def test_unified_fp8_output(oracle):
+    c = make_unified_case([(130, 500), (1, 90)], 8, 2, 128, 16, torch.bfloat16, fp8=True, seed=9,
+                          kv_scale=0.5)
+    run(oracle, c, torch.bfloat16, fp8=True, out_scale=torch.tensor([0.02]))
+
+
+def test_unified_strided_cache(oracle):
+    """Caches as permuted views of an HND allocation (strides, not shapes, address the cache)."""
+    c = make_unified_case([(70, 300), (3, 50)], 4, 2, 128, 16, torch.bfloat16, seed=11)
+    view = lambda t: t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+    run(oracle, c, torch.bfloat16, view=view)
+
+
+def test_unified_rejects_what_it_does_not_cover():
+    from vllm_amd.attention.ops import unified_attention
+    c = make_unified_case([(4, 40)], 4, 4, 256, 16, torch.bfloat16)
+    out = torch.zeros(c["q"].shape, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="unsupported head size"):
+        unified_attention(c["q"].cuda(), c["k"].cuda(), c["v"].cuda(), out, c["cu_seqlens_q"].cuda(),
+                          4, c["seqused_k"].cuda(), 40, 0.1, True, (-1, -1), c["block_table"].cuda(),
+                          0, None, None, None)

@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
-"""context_attention_fwd timing: python tools/bench_prefill.py [--kv fp8|auto]"""
+"""context_attention_fwd / unified_attention timing:
+python tools/bench_prefill.py [--kv fp8|auto] [--unified]"""
 import argparse, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from vllm_amd.attention.ops import context_attention_fwd
+from vllm_amd.attention.ops import context_attention_fwd, unified_attention
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--kv", default="fp8")
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--unified", action="store_true", help="unified_attention over a flash-layout cache")
 ap.add_argument("--rows", type=int, default=0, help="query rows per workgroup (tuning pf_rows)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -38,7 +40,18 @@ for (B, ql, cl) in ((4, 2048, 0), (4, 2048, 2048), (1, 8192, 0), (16, 512, 3584)
     seql = torch.full((B,), ql + cl, dtype=torch.int32, device=dev)
     one = torch.full((1,), 0.02, device=dev)
     fn = lambda: context_attention_fwd(q, k, v, o, a.kv, kc, vc, b_loc, start, seql, ql + cl, ql, one, one)
+    if a.unified:
+        nb_u = (ql + cl + BS - 1) // BS
+        if fp8:
+            kf = torch.randint(0, 120, (B * nb_u, BS, KVH, D), device=dev, dtype=torch.uint8)
+            vf = torch.randint(0, 120, (B * nb_u, BS, KVH, D), device=dev, dtype=torch.uint8)
+        else:
+            kf = (torch.rand((B * nb_u, BS, KVH, D), device=dev) - 0.5).to(torch.bfloat16)
+            vf = (torch.rand((B * nb_u, BS, KVH, D), device=dev) - 0.5).to(torch.bfloat16)
+        bt = torch.randperm(B * nb_u, device=dev).to(torch.int32).view(B, nb_u)
+        fn = lambda: unified_attention(q, kf, vf, o, start, ql, seql, ql + cl, D ** -0.5, True, (-1, -1),
+                                       bt, 0.0, None, one if fp8 else None, one if fp8 else None)
     t = bench.time_gpu_graph(fn, a.iters)
     flops = 4.0 * D * H * B * ql * (cl + (ql + 1) / 2)
-    print(f"B={B:3d} q_len={ql:5d} ctx={cl:5d} kv={a.kv}: {t*1e6:9.1f} us  {flops/t/1e12:7.1f} TFLOP/s "
+    print(f"{'unified ' if a.unified else ''}B={B:3d} q_len={ql:5d} ctx={cl:5d} kv={a.kv}: {t*1e6:9.1f} us  {flops/t/1e12:7.1f} TFLOP/s "
           f"({100*flops/t/2.5e15:.1f}% of 2.5 PF bf16)", flush=True)

@@ -37,6 +37,9 @@ struct PrefillParams {
   int64_t b_loc_stride, q_stride_t, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h,
       o_stride_t, o_stride_h, kc_block_bytes, kc_head_bytes, vc_block_bytes, vc_head_bytes;
   float sm_scale; int sliding_window; int skip_decode;
+  // unified_attention only (UNI): flash-layout cache [block][slot][head][d], softcap
+  int64_t kc_page_bytes, vc_page_bytes;
+  float softcap;
 };
 
 // transposing 8-byte LDS read (4 x 16 bit), see compute_tile
@@ -50,7 +53,13 @@ __device__ __forceinline__ uint2 lds_read_tr16(const uint8_t* p) {
 // MT = 16-row query tiles per wave: 2 -> 4 waves of 32 rows (each K / V fragment feeds two
 // MFMAs), 1 -> 8 waves of 16 rows (half the registers per wave: no spills at head size 128).
 // NW = waves per workgroup: the workgroup owns PF_BM = 16 MT NW query rows.
-template <typename T, bool FP8, int D, int BS, int MT, int NW>
+//
+// UNI = unified_attention (vllm/attention/ops/triton_unified_attention.py:52-272, 588-700):
+// there are no separate new-token K / V -- every key comes from the cache, which is in the
+// FLASH layout [block][slot][kv head][d] -- and the causal bound is position-based
+// (key n visible to query m iff n <= ctx + m).  Every KV tile is staged like the new tokens of
+// the prefix kernel (K and V row-major, V read with the transposing LDS load).
+template <typename T, bool FP8, int D, int BS, int MT, int NW, bool UNI = false>
 __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams p) {
   constexpr int PF_THREADS = 64 * NW, PF_BM = 16 * MT * NW;
   static_assert(D % 32 == 0 && D <= 128, "");
@@ -103,7 +112,9 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
 
   const bool alibi = p.alibi_slopes != nullptr;
   const float slope2 = alibi ? p.alibi_slopes[head] * kLog2e : 0.f;
-  const int window = alibi ? 0 : p.sliding_window;   // the alibi kernel has no window
+  // the prefix kernel's alibi variant has no window; unified_attention applies both
+  const int window = (alibi && !UNI) ? 0 : p.sliding_window;
+  const float softcap = UNI ? p.softcap : 0.f;
   const float sc2 = p.sm_scale * kLog2e;
   float kscale = 1.f, vscale = 1.f;
   if constexpr (FP8) { kscale = *p.k_scale; vscale = *p.v_scale; }
@@ -135,9 +146,10 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
     for (int i = 0; i < DT; ++i) o[i][mt] = (f32x4){0, 0, 0, 0};
   }
 
-  const int ctx_tiles = (ctx + PF_BN - 1) / PF_BN;
   const int new_end = min((start_m + 1) * PF_BM, qlen);      // causal bound of this row block
-  const int new_tiles = (new_end + PF_BN - 1) / PF_BN;
+  // UNI: no context tiles in the prefix kernel's sense; tiles cover keys [0, ctx + new_end)
+  const int ctx_tiles = UNI ? 0 : (ctx + PF_BN - 1) / PF_BN;
+  const int new_tiles = ((UNI ? ctx + new_end : new_end) + PF_BN - 1) / PF_BN;
   const int ntiles = ctx_tiles + new_tiles;
   const int* bl = p.b_loc + (int64_t)seq * p.b_loc_stride;
 
@@ -155,18 +167,18 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   constexpr int PPT = PF_BN / BS;   // pages per tile
   constexpr int VPG = FP8 ? V8_ITEMS : V16_ITEMS;
   struct Pages { int k; int v[VPG]; };
-  const int last_page = ctx > 0 ? (ctx - 1) / BS : 0;
+  const int last_page = UNI ? (seq_len > 0 ? (seq_len - 1) / BS : 0) : (ctx > 0 ? (ctx - 1) / BS : 0);
   auto v_page_of_item = [&](int i) {   // page (within the tile) of V item i of this thread
     constexpr int CPP = FP8 ? BS / 16 : BS / 8;
     return min((tid + PF_THREADS * i) / (CPP * D), PPT - 1);
   };
   auto load_pages = [&](int t) {
     Pages pg;
-    const bool on = t < ctx_tiles;
+    const bool on = UNI ? t < ntiles : t < ctx_tiles;
     pg.k = on ? bl[min(t * PPT + (tid & 63) / BS, last_page)] : 0;
     static_for<VPG>([&](auto ic_) {
       constexpr int i = decltype(ic_)::value;
-      pg.v[i] = on ? bl[min(t * PPT + v_page_of_item(i), last_page)] : 0;
+      pg.v[i] = (on && !UNI) ? bl[min(t * PPT + v_page_of_item(i), last_page)] : 0;
     });
     return pg;
   };
@@ -174,7 +186,30 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   // ---- global -> registers: raw loads only (masks and conversions happen in store_tile, so
   // nothing here waits for the data) ---------------------------------------------------------
   auto load_tile = [&](int t, const Pages& pg) {
-    if (t < ctx_tiles) {
+    if constexpr (UNI) {
+      // every item of a thread is the same token (PF_THREADS is a multiple of 64): one page
+      const int tok = tid & 63;
+      const uint8_t* krow = p.k_cache + (int64_t)pg.k * p.kc_block_bytes +
+                            (int64_t)(tok % BS) * p.kc_page_bytes + (int64_t)kvh * p.kc_head_bytes;
+      const uint8_t* vrow = p.v_cache + (int64_t)pg.k * p.vc_block_bytes +
+                            (int64_t)(tok % BS) * p.vc_page_bytes + (int64_t)kvh * p.vc_head_bytes;
+      if constexpr (!FP8) {
+        static_for<K16_ITEMS>([&](auto ic_) {
+          constexpr int i = decltype(ic_)::value;            // item -> (tok, 8-element chunk)
+          const int item = min(tid + PF_THREADS * i, K16_TOTAL - 1);
+          const int c = min(item >> 6, dr / 8 - 1);
+          kst[i] = *reinterpret_cast<const u32x4*>(krow + 16 * c);
+          vst[i] = *reinterpret_cast<const u32x4*>(vrow + 16 * c);
+        });
+      } else {
+        static_for<K8_ITEMS>([&](auto ic_) {
+          constexpr int i = decltype(ic_)::value;            // item -> (tok, 16-element chunk)
+          const int cc = min((tid + PF_THREADS * i) >> 6, dr / 16 - 1);
+          kst[i] = *reinterpret_cast<const u32x4*>(krow + 16 * cc);
+          vst[i] = *reinterpret_cast<const u32x4*>(vrow + 16 * cc);
+        });
+      }
+    } else if (t < ctx_tiles) {
       if constexpr (!FP8) {
         static_for<K16_ITEMS>([&](auto ic_) {
           constexpr int i = decltype(ic_)::value;          // item -> (tok = item & 63, chunk)
@@ -242,7 +277,36 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   constexpr int VNSWZ = (KCH % 16 == 0) ? 7 : (KCH % 8 == 0) ? 3 : 1;   // stays inside the row
   auto vn_slot = [&](int tok, int c) { return lds_v + tok * KROW + ((c ^ (2 * (tok & VNSWZ))) << 4); };
   auto store_tile = [&](int t) {
-    if (t < ctx_tiles) {
+    if constexpr (UNI) {
+      // slots past the sequence hold stale bytes (possibly NaN): V rows of such keys are zeroed
+      const int tok = tid & 63;
+      const bool live = t * PF_BN + tok < seq_len;
+      if constexpr (!FP8) {
+        static_for<K16_ITEMS>([&](auto ic_) {
+          constexpr int i = decltype(ic_)::value;
+          const int item = tid + PF_THREADS * i;
+          const int c = item >> 6;
+          if (item < K16_TOTAL) {
+            *reinterpret_cast<u32x4*>(k_slot(tok, c)) = c < dr / 8 ? kst[i] : (u32x4){0, 0, 0, 0};
+            *reinterpret_cast<u32x4*>(vn_slot(tok, c)) = (live && c < dr / 8) ? vst[i] : (u32x4){0, 0, 0, 0};
+          }
+        });
+      } else {
+        static_for<K8_ITEMS>([&](auto ic_) {
+          constexpr int i = decltype(ic_)::value;
+          const int cc = (tid + PF_THREADS * i) >> 6;
+          if (cc < D / 16) {
+            uint4 lo, hi;   // exact widening; the scales ride in the score scale / the exponent
+            widen16<T>(as_u4(cc < dr / 16 ? kst[i] : (u32x4){0, 0, 0, 0}), lo, hi);
+            *reinterpret_cast<uint4*>(k_slot(tok, 2 * cc)) = lo;
+            *reinterpret_cast<uint4*>(k_slot(tok, 2 * cc + 1)) = hi;
+            widen16<T>(as_u4((live && cc < dr / 16) ? vst[i] : (u32x4){0, 0, 0, 0}), lo, hi);
+            *reinterpret_cast<uint4*>(vn_slot(tok, 2 * cc)) = lo;
+            *reinterpret_cast<uint4*>(vn_slot(tok, 2 * cc + 1)) = hi;
+          }
+        });
+      }
+    } else if (t < ctx_tiles) {
       if constexpr (!FP8) {
         static_for<K16_ITEMS>([&](auto ic_) {
           constexpr int i = decltype(ic_)::value;
@@ -330,12 +394,13 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   // reference's (fp8 * scale).to(dtype), inside the stated tolerance.
   auto compute_tile = [&](int t, auto masked_c) {
     constexpr bool MASKED = decltype(masked_c)::value;
-    const bool is_ctx = t < ctx_tiles;
+    const bool is_ctx = t < ctx_tiles;   // never with UNI: its tiles take the row-major V path
     const int n0 = is_ctx ? t * PF_BN : (t - ctx_tiles) * PF_BN;
-    const float sct = (FP8 && is_ctx) ? sc2 * kscale : sc2;        // score scale of this tile
+    const bool scaled = FP8 && (UNI || is_ctx);                     // fp8 keys / values in this tile
+    const float sct = scaled ? sc2 * kscale : sc2;                  // score scale of this tile
     // value scale of this tile, as log2 and as reciprocal (1 for new tokens)
-    const float pv_log2 = (FP8 && is_ctx) ? vscale_log2 : 0.f;
-    const float pv_inv = (FP8 && is_ctx) ? vscale_inv : 1.f;
+    const float pv_log2 = scaled ? vscale_log2 : 0.f;
+    const float pv_inv = scaled ? vscale_inv : 1.f;
     f32x4 s[4][MT];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -361,6 +426,24 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int n = n0 + 16 * nt + 4 * g4 + r;
+            if constexpr (UNI) {
+              // triton_unified_attention.py:219-238: softcap, causal + padding mask, window,
+              // then the ALiBi bias slope * (key position - context_len)
+              float x = s[nt][mt][r] * sct;
+              if (softcap > 0.f) {
+                // softcap * tanh(S / softcap), S = scale * q.k; tanh from one exp2 of -2|y|
+                const float y = x * (1.0f / kLog2e) / softcap;
+                const float e2 = fast_exp2(-2.0f * kLog2e * fabsf(y));
+                x = copysignf(softcap * kLog2e * (1.0f - e2) / (1.0f + e2), y);
+              }
+              bool valid = n <= ctx + m && m < qlen;
+              if (window > 0 && ctx + m - n >= window) valid = false;
+              if (alibi) x += (float)(n - ctx) * slope2;
+              x = valid ? x : -INFINITY;
+              s[nt][mt][r] = x;
+              mx = fmaxf(mx, x);
+              continue;
+            }
             const int kpos = is_ctx ? n : ctx + n;
             // context: every cached token is visible; new tokens: causal (prefix_prefill.py:175, 249)
             const bool valid = is_ctx ? n < ctx : n <= m;
@@ -448,6 +531,14 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   // the wave's rows), 1 = interior, 2 = masked
   const int m_hi = m_wave + 16 * MT - 1;       // last query row of the wave
   auto tile_kind = [&](int t) {
+    if constexpr (UNI) {
+      const int n0 = t * PF_BN;
+      if (n0 > ctx + m_hi) return 0;                                       // above the diagonal
+      if (window > 0 && n0 + PF_BN - 1 < ctx + m_wave - window + 1) return 0;   // left of the window
+      if (alibi || softcap > 0.f) return 2;
+      if (n0 + PF_BN - 1 > ctx + m_wave || m_hi >= qlen) return 2;
+      return (window > 0 && ctx + m_hi - n0 >= window) ? 2 : 1;
+    }
     if (alibi) return 2;
     if (t < ctx_tiles) {
       const int n0 = t * PF_BN;
@@ -487,7 +578,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
     l += __shfl_xor(l, 32, 64);
     const int m = m_wave + 16 * mt + c16;
     if (m >= qlen) continue;
-    const float inv = 1.0f / l;   // acc / l_i (:276)
+    const float inv = l > 0.f ? 1.0f / l : 0.f;   // acc / l_i (:276); a fully masked row gives 0
     if (!fp8_out) {
       T* op = (T*)p.o + (int64_t)(tok0 + m) * p.o_stride_t + (int64_t)head * p.o_stride_h;
 #pragma unroll
@@ -513,15 +604,22 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   }
 }
 
-template <typename T, bool FP8, int D, int MT, int NW>
+template <typename T, bool FP8, int D, int MT, int NW, bool UNI = false>
 static void launch_cfg(const PrefillParams& p, int block_size, int max_input_len, int num_heads,
                        int batch, hipStream_t st) {
   constexpr int BM = 16 * MT * NW;
   const dim3 grid((max_input_len + BM - 1) / BM, num_heads, batch);
   if (block_size == 16)
-    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 16, MT, NW>), grid, dim3(64 * NW), 0, st, p);
+    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 16, MT, NW, UNI>), grid, dim3(64 * NW), 0, st, p);
   else
-    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 32, MT, NW>), grid, dim3(64 * NW), 0, st, p);
+    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 32, MT, NW, UNI>), grid, dim3(64 * NW), 0, st, p);
+}
+// unified_attention: padded head sizes 64 and 128 (one configuration each)
+template <typename T, bool FP8>
+static void launch_unified(const PrefillParams& p, int head_size, int block_size, int max_q,
+                           int num_heads, int batch, hipStream_t st) {
+  if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true>(p, block_size, max_q, num_heads, batch, st);
+  else launch_cfg<T, FP8, 128, 1, 4, true>(p, block_size, max_q, num_heads, batch, st);
 }
 template <typename T, bool FP8, int D>
 static void launch_bs(const PrefillParams& p, int block_size, int max_input_len, int num_heads,
@@ -606,6 +704,8 @@ extern "C" int vllm_amd_context_attention_fwd(
   p.sm_scale = sm_scale;
   p.sliding_window = sliding_window > 0 ? sliding_window : 0;
   p.skip_decode = skip_decode;
+  p.kc_page_bytes = p.vc_page_bytes = 0;
+  p.softcap = 0.f;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VLLM_AMD_BF16) {
     if (es == 2) launch_d<bf16_t, false>(p, head_size, block_size, max_input_len, num_heads, batch, st);
@@ -613,6 +713,79 @@ extern "C" int vllm_amd_context_attention_fwd(
   } else {
     if (es == 2) launch_d<f16_t, false>(p, head_size, block_size, max_input_len, num_heads, batch, st);
     else launch_d<f16_t, true>(p, head_size, block_size, max_input_len, num_heads, batch, st);
+  }
+  VA_LAUNCH_CHECK(op);
+  return VLLM_AMD_OK;
+}
+
+// unified_attention (vllm/attention/ops/triton_unified_attention.py:588-700): q over the new
+// tokens of every sequence, all keys / values from the flash-layout cache, causal.
+extern "C" int vllm_amd_unified_attention(
+    void* out, const void* q, const void* k_cache, const void* v_cache, const int* cu_seqlens_q,
+    const int* seqused_k, const int* block_table, const float* k_descale, const float* v_descale,
+    const float* alibi_slopes, const float* output_scale, int num_seqs, int num_heads,
+    int num_kv_heads, int head_size, int block_size, int max_seqlen_q, int64_t block_table_stride,
+    int64_t q_stride_t, int64_t q_stride_h, int64_t o_stride_t, int64_t o_stride_h,
+    int64_t kc_stride_block, int64_t kc_stride_slot, int64_t kc_stride_head,
+    int64_t vc_stride_block, int64_t vc_stride_slot, int64_t vc_stride_head, float softmax_scale,
+    int sliding_window, float softcap, int dtype, int kv_cache_dtype, void* stream) {
+  const char* op = "unified_attention";
+  VA_REQUIRE(num_seqs >= 0 && max_seqlen_q >= 0, VLLM_AMD_EINVAL, "%s: negative size", op);
+  if (num_seqs == 0 || max_seqlen_q == 0 || num_heads == 0) return VLLM_AMD_OK;
+  VA_REQUIRE(out && q && k_cache && v_cache && cu_seqlens_q && seqused_k && block_table,
+             VLLM_AMD_EINVAL, "%s: null pointer", op);
+  VA_REQUIRE(dtype == VLLM_AMD_F16 || dtype == VLLM_AMD_BF16, VLLM_AMD_EUNSUPPORTED,
+             "%s: query dtype must be float16 or bfloat16", op);
+  VA_REQUIRE(kv_cache_dtype == VLLM_AMD_KV_AUTO || kv_cache_dtype == VLLM_AMD_KV_FP8_E4M3,
+             VLLM_AMD_EUNSUPPORTED, "Unsupported FP8 dtype: %d", kv_cache_dtype);
+  const int es = kv_cache_dtype == VLLM_AMD_KV_AUTO ? 2 : 1;
+  VA_REQUIRE(head_size >= 8 && head_size <= 128 && head_size % (es == 2 ? 8 : 16) == 0,
+             VLLM_AMD_EUNSUPPORTED,
+             "%s: unsupported head size: %d (multiples of 8, of 16 with an fp8 cache, up to 128)",
+             op, head_size);
+  VA_REQUIRE(block_size == 16 || block_size == 32, VLLM_AMD_EUNSUPPORTED,
+             "%s: unsupported block size: %d (16, 32)", op, block_size);
+  VA_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, VLLM_AMD_EINVAL,
+             "%s: num_heads must be a multiple of num_kv_heads", op);
+  VA_REQUIRE(es == 2 || (k_descale && v_descale), VLLM_AMD_EINVAL,
+             "%s: fp8 cache needs k_descale and v_descale", op);
+  VA_REQUIRE(softcap >= 0.f && sliding_window >= 0, VLLM_AMD_EINVAL,
+             "%s: softcap and sliding_window must not be negative", op);
+  const int ca = 16 / es;   // cache elements per 16 bytes
+  VA_REQUIRE(q_stride_t % 8 == 0 && q_stride_h % 8 == 0 && o_stride_t % 4 == 0 &&
+                 o_stride_h % 4 == 0 && kc_stride_block % ca == 0 && kc_stride_slot % ca == 0 &&
+                 kc_stride_head % ca == 0 && vc_stride_block % ca == 0 &&
+                 vc_stride_slot % ca == 0 && vc_stride_head % ca == 0 &&
+                 (((uintptr_t)q) & 15) == 0 && (((uintptr_t)out) & 7) == 0 &&
+                 (((uintptr_t)k_cache) & 15) == 0 && (((uintptr_t)v_cache) & 15) == 0,
+             VLLM_AMD_EUNSUPPORTED, "%s: tensors must be 16-byte aligned with 16-byte strides", op);
+  PrefillParams p;
+  p.o = out; p.q = q; p.k = q; p.v = q;   // no separate new-token K / V
+  p.k_cache = (const uint8_t*)k_cache; p.v_cache = (const uint8_t*)v_cache;
+  p.b_loc = block_table; p.b_start_loc = cu_seqlens_q; p.b_seq_len = seqused_k;
+  p.k_scale = k_descale; p.v_scale = v_descale; p.alibi_slopes = alibi_slopes;
+  p.fp8_out_scale = output_scale;
+  p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
+  p.head_size = head_size;
+  p.b_loc_stride = block_table_stride;
+  p.q_stride_t = q_stride_t; p.q_stride_h = q_stride_h;
+  p.k_stride_t = p.k_stride_h = p.v_stride_t = p.v_stride_h = 0;
+  p.o_stride_t = o_stride_t; p.o_stride_h = o_stride_h;
+  p.kc_block_bytes = kc_stride_block * es; p.kc_page_bytes = kc_stride_slot * es;
+  p.kc_head_bytes = kc_stride_head * es;
+  p.vc_block_bytes = vc_stride_block * es; p.vc_page_bytes = vc_stride_slot * es;
+  p.vc_head_bytes = vc_stride_head * es;
+  p.sm_scale = softmax_scale;
+  p.sliding_window = sliding_window;
+  p.skip_decode = 0;
+  p.softcap = softcap;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VLLM_AMD_BF16) {
+    if (es == 2) launch_unified<bf16_t, false>(p, head_size, block_size, max_seqlen_q, num_heads, num_seqs, st);
+    else launch_unified<bf16_t, true>(p, head_size, block_size, max_seqlen_q, num_heads, num_seqs, st);
+  } else {
+    if (es == 2) launch_unified<f16_t, false>(p, head_size, block_size, max_seqlen_q, num_heads, num_seqs, st);
+    else launch_unified<f16_t, true>(p, head_size, block_size, max_seqlen_q, num_heads, num_seqs, st);
   }
   VA_LAUNCH_CHECK(op);
   return VLLM_AMD_OK;
