@@ -171,3 +171,22 @@ def test_validation_errors_of_the_neighbour_ops():
     assert "Unsupported FP8 dtype" in _err(pf(kv=5))
     assert "multiple of num_kv_heads" in _err(pf(heads=8, kvh=3))
     assert "16-byte aligned" in _err(pf(qs=1021))
+
+    # unified attention (flash-layout cache)
+    def ua(head_size=128, block_size=16, dtype=_lib.BF16, kv=_lib.KV_AUTO, heads=8, kvh=2, seqs=1,
+           qs=1024, window=0, softcap=0.0, kd=p):
+        return L.vllm_amd_unified_attention(
+            p, p, p, p, p, p, p, kd, kd, None, None, seqs, heads, kvh, head_size, block_size, 64,
+            16, qs, head_size, heads * head_size, head_size, block_size * kvh * head_size,
+            kvh * head_size, head_size, block_size * kvh * head_size, kvh * head_size, head_size,
+            0.1, window, softcap, dtype, kv, None)
+    assert ua(seqs=0) == 0
+    assert "unsupported head size: 256" in _err(ua(head_size=256))
+    assert "unsupported head size: 40" in _err(ua(head_size=40, kv=_lib.KV_FP8_E4M3, qs=320))
+    assert "unsupported block size: 64" in _err(ua(block_size=64))
+    assert "float16 or bfloat16" in _err(ua(dtype=_lib.F32))
+    assert "Unsupported FP8 dtype" in _err(ua(kv=7))
+    assert "k_descale and v_descale" in _err(ua(kv=_lib.KV_FP8_E4M3, kd=None))
+    assert "must not be negative" in _err(ua(softcap=-1.0))
+    assert "16-byte" in _err(ua(qs=1020))
+
