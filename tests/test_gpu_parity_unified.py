@@ -88,6 +88,37 @@ def test_unified_alibi(oracle, window):
     run(oracle, c, torch.float16, alibi=slopes, window=window)
 
 
+@pytest.mark.parametrize("heads", [(8, 2), (32, 8), (16, 1), (6, 2)])
+@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("mode", ["plain", "window", "alibi", "softcap"])
+def test_unified_decode_batches(oracle, heads, D, fp8, mode):
+    """Decode-only batches (every query length 1) take the GQA-packed launch: tile rows = the
+    q heads of a kv head's group.  Lengths around the 64-key tile and the page size."""
+    c = make_unified_case([(1, 1), (1, 64), (1, 65), (1, 300), (1, 17), (1, 1000)], heads[0], heads[1],
+                          D, 16, torch.bfloat16, fp8=fp8, seed=heads[0] + D, kv_scale=0.5)
+    slopes = 2.0 ** -(torch.arange(heads[0]).float() * 0.25 + 1) if mode == "alibi" else None
+    run(oracle, c, torch.bfloat16, fp8=fp8, alibi=slopes, window=48 if mode == "window" else None,
+        softcap=20.0 if mode == "softcap" else 0.0)
+
+
+def test_unified_decode_packed_equals_unpacked(oracle):
+    """Same decode batch through the packed and the per-head launch ("pf_rows" = 1)."""
+    from vllm_amd import _lib
+    from vllm_amd.attention.ops import unified_attention
+    c = make_unified_case([(1, 700), (1, 33)], 16, 4, 128, 32, torch.float16, seed=4)
+    outs = []
+    for knob in (0, 1):
+        _lib.set_tuning("pf_rows", knob)
+        out = torch.zeros(c["q"].shape, dtype=torch.float16, device="cuda")
+        unified_attention(c["q"].cuda(), c["k"].cuda(), c["v"].cuda(), out, c["cu_seqlens_q"].cuda(), 1,
+                          c["seqused_k"].cuda(), 700, 128 ** -0.5, True, (-1, -1),
+                          c["block_table"].cuda(), 0.0, None, None, None)
+        outs.append(out.cpu())
+    _lib.set_tuning("pf_rows", 0)
+    torch.testing.assert_close(outs[0].float(), outs[1].float(), atol=2e-3, rtol=2e-3)
+
+
 def test_unified_fp8_output(oracle):
     c = make_unified_case([(130, 500), (1, 90)], 8, 2, 128, 16, torch.bfloat16, fp8=True, seed=9,
                           kv_scale=0.5)

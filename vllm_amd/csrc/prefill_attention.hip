@@ -59,8 +59,13 @@ __device__ __forceinline__ uint2 lds_read_tr16(const uint8_t* p) {
 // FLASH layout [block][slot][kv head][d] -- and the causal bound is position-based
 // (key n visible to query m iff n <= ctx + m).  Every KV tile is staged like the new tokens of
 // the prefix kernel (K and V row-major, V read with the transposing LDS load).
-template <typename T, bool FP8, int D, int BS, int MT, int NW, bool UNI = false>
+// PACK (with UNI, decode-only batches: every sequence has ONE query token): the rows of the
+// query tile are the q heads of one kv head's GQA group instead of the tokens of one head
+// (the reference packs BLOCK_M / num_queries_per_kv tokens x the group, :612-613), so the
+// group's K / V are streamed once; grid.y = kv heads.
+template <typename T, bool FP8, int D, int BS, int MT, int NW, bool UNI = false, bool PACK = false>
 __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams p) {
+  static_assert(!PACK || UNI, "");
   constexpr int PF_THREADS = 64 * NW, PF_BM = 16 * MT * NW;
   static_assert(D % 32 == 0 && D <= 128, "");
   // D = head size padded to a multiple of 32: chunks at d >= dr are staged as zeros (K, Q: no
@@ -100,8 +105,12 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
     wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
   const int start_m = gridDim.x - 1 - wg % gridDim.x;
+  const int gqa = p.num_heads / p.num_kv_heads;
   const int head = (wg / gridDim.x) % gridDim.y, seq = wg / (gridDim.x * gridDim.y);
-  const int kvh = head / (p.num_heads / p.num_kv_heads);
+  const int kvh = PACK ? head : head / gqa;
+  // tile row m -> (query token within the sequence's new tokens, q head, is it a real row)
+  auto row_tok = [&](int m) { return PACK ? 0 : m; };
+  auto row_head = [&](int m) { return PACK ? kvh * gqa + (m < gqa ? m : 0) : head; };
 
   const int seq_len = p.b_seq_len[seq];
   const int tok0 = p.b_start_loc[seq];
@@ -109,9 +118,10 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   const int ctx = seq_len - qlen;
   if (p.skip_decode && qlen == 1) return;
   if (start_m * PF_BM >= qlen) return;   // the reference computes and stores nothing here
+  auto row_valid = [&](int m) { return PACK ? m < gqa : m < qlen; };
 
   const bool alibi = p.alibi_slopes != nullptr;
-  const float slope2 = alibi ? p.alibi_slopes[head] * kLog2e : 0.f;
+  const float slope2 = (alibi && !PACK) ? p.alibi_slopes[head] * kLog2e : 0.f;
   // the prefix kernel's alibi variant has no window; unified_attention applies both
   const int window = (alibi && !UNI) ? 0 : p.sliding_window;
   const float softcap = UNI ? p.softcap : 0.f;
@@ -126,16 +136,20 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m_wave + 16 * mt + c16;
-    const T* qp = (const T*)p.q + (int64_t)(tok0 + (m < qlen ? m : 0)) * p.q_stride_t +
-                  (int64_t)head * p.q_stride_h;
+    const T* qp = (const T*)p.q + (int64_t)(tok0 + (row_valid(m) ? row_tok(m) : 0)) * p.q_stride_t +
+                  (int64_t)row_head(m) * p.q_stride_h;
 #pragma unroll
     for (int ks = 0; ks < QK_STEPS; ++ks) {
       const int d0 = 32 * ks + 8 * g4;
       const uint4 v = *reinterpret_cast<const uint4*>(qp + (d0 < dr ? d0 : 0));
-      qf[mt][ks] = (m < qlen && d0 < dr) ? v : make_uint4(0, 0, 0, 0);
+      qf[mt][ks] = (row_valid(m) && d0 < dr) ? v : make_uint4(0, 0, 0, 0);
     }
   }
 
+  float slope_row[MT];   // PACK: one ALiBi slope per tile row (= q head)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+    slope_row[mt] = (PACK && alibi) ? p.alibi_slopes[row_head(m_wave + 16 * mt + c16)] * kLog2e : 0.f;
   float m_run[MT], l_run[MT];
   f32x4 o[DT][MT];
 #pragma unroll
@@ -146,7 +160,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
     for (int i = 0; i < DT; ++i) o[i][mt] = (f32x4){0, 0, 0, 0};
   }
 
-  const int new_end = min((start_m + 1) * PF_BM, qlen);      // causal bound of this row block
+  const int new_end = PACK ? 1 : min((start_m + 1) * PF_BM, qlen);   // causal bound of this row block
   // UNI: no context tiles in the prefix kernel's sense; tiles cover keys [0, ctx + new_end)
   const int ctx_tiles = UNI ? 0 : (ctx + PF_BN - 1) / PF_BN;
   const int new_tiles = ((UNI ? ctx + new_end : new_end) + PF_BN - 1) / PF_BN;
@@ -436,9 +450,9 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
                 const float e2 = fast_exp2(-2.0f * kLog2e * fabsf(y));
                 x = copysignf(softcap * kLog2e * (1.0f - e2) / (1.0f + e2), y);
               }
-              bool valid = n <= ctx + m && m < qlen;
-              if (window > 0 && ctx + m - n >= window) valid = false;
-              if (alibi) x += (float)(n - ctx) * slope2;
+              bool valid = n <= ctx + row_tok(m) && row_valid(m);
+              if (window > 0 && ctx + row_tok(m) - n >= window) valid = false;
+              if (alibi) x += (float)(n - ctx) * (PACK ? slope_row[mt] : slope2);
               x = valid ? x : -INFINITY;
               s[nt][mt][r] = x;
               mx = fmaxf(mx, x);
@@ -533,11 +547,13 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   auto tile_kind = [&](int t) {
     if constexpr (UNI) {
       const int n0 = t * PF_BN;
-      if (n0 > ctx + m_hi) return 0;                                       // above the diagonal
-      if (window > 0 && n0 + PF_BN - 1 < ctx + m_wave - window + 1) return 0;   // left of the window
+      if (PACK && m_wave >= gqa) return 0;          // this wave has no q head: it only stages
+      const int p_lo = PACK ? 0 : m_wave, p_hi = PACK ? 0 : m_hi;   // query positions - ctx
+      if (n0 > ctx + p_hi) return 0;                                       // above the diagonal
+      if (window > 0 && n0 + PF_BN - 1 < ctx + p_lo - window + 1) return 0;   // left of the window
       if (alibi || softcap > 0.f) return 2;
-      if (n0 + PF_BN - 1 > ctx + m_wave || m_hi >= qlen) return 2;
-      return (window > 0 && ctx + m_hi - n0 >= window) ? 2 : 1;
+      if (n0 + PF_BN - 1 > ctx + p_lo || (!PACK && m_hi >= qlen)) return 2;
+      return (window > 0 && ctx + p_hi - n0 >= window) ? 2 : 1;
     }
     if (alibi) return 2;
     if (t < ctx_tiles) {
@@ -577,10 +593,10 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const int m = m_wave + 16 * mt + c16;
-    if (m >= qlen) continue;
+    if (!row_valid(m)) continue;
     const float inv = l > 0.f ? 1.0f / l : 0.f;   // acc / l_i (:276); a fully masked row gives 0
     if (!fp8_out) {
-      T* op = (T*)p.o + (int64_t)(tok0 + m) * p.o_stride_t + (int64_t)head * p.o_stride_h;
+      T* op = (T*)p.o + (int64_t)(tok0 + row_tok(m)) * p.o_stride_t + (int64_t)row_head(m) * p.o_stride_h;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         if (16 * dt + 4 * g4 >= dr) continue;
@@ -590,7 +606,8 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
       }
     } else {
       // acc / out_scale, clamp to the fp8 range, store e4m3 (:282-287)
-      uint8_t* op = (uint8_t*)p.o + (int64_t)(tok0 + m) * p.o_stride_t + (int64_t)head * p.o_stride_h;
+      uint8_t* op = (uint8_t*)p.o + (int64_t)(tok0 + row_tok(m)) * p.o_stride_t +
+                    (int64_t)row_head(m) * p.o_stride_h;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         if (16 * dt + 4 * g4 >= dr) continue;
@@ -604,20 +621,27 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   }
 }
 
-template <typename T, bool FP8, int D, int MT, int NW, bool UNI = false>
+template <typename T, bool FP8, int D, int MT, int NW, bool UNI = false, bool PACK = false>
 static void launch_cfg(const PrefillParams& p, int block_size, int max_input_len, int num_heads,
                        int batch, hipStream_t st) {
   constexpr int BM = 16 * MT * NW;
   const dim3 grid((max_input_len + BM - 1) / BM, num_heads, batch);
   if (block_size == 16)
-    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 16, MT, NW, UNI>), grid, dim3(64 * NW), 0, st, p);
+    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 16, MT, NW, UNI, PACK>), grid, dim3(64 * NW), 0, st, p);
   else
-    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 32, MT, NW, UNI>), grid, dim3(64 * NW), 0, st, p);
+    hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 32, MT, NW, UNI, PACK>), grid, dim3(64 * NW), 0, st, p);
 }
 // unified_attention: padded head sizes 64 and 128 (one configuration each)
 template <typename T, bool FP8>
 static void launch_unified(const PrefillParams& p, int head_size, int block_size, int max_q,
                            int num_heads, int batch, hipStream_t st) {
+  // decode-only batch: rows = the GQA group's q heads (grid.y = kv heads), if the group fits
+  const int gqa = p.num_heads / p.num_kv_heads;
+  if (max_q == 1 && gqa > 1 && gqa <= 64 && g_pf_rows != 1) {
+    if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true, true>(p, block_size, 1, p.num_kv_heads, batch, st);
+    else launch_cfg<T, FP8, 128, 1, 4, true, true>(p, block_size, 1, p.num_kv_heads, batch, st);
+    return;
+  }
   if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true>(p, block_size, max_q, num_heads, batch, st);
   else launch_cfg<T, FP8, 128, 1, 4, true>(p, block_size, max_q, num_heads, batch, st);
 }
