@@ -309,9 +309,9 @@ int vllm_amd_context_attention_fwd(
  *   sliding_window = 1 + window_size[0] of the reference call (0 = none) (:655)
  * Supported here: f16 / bf16 queries (no fp8 queries: q_descale is "not supported" in the
  * reference either, :609), head_size a multiple of 8 (16 with an fp8 cache) up to 128,
- * block_size 16 / 32.  Decode-only batches (max_seqlen_q == 1) are launched with the GQA
- * group packed into the tile rows; no split over the keys (the paged_attention_* ops above
- * remain the fastest decode path). */
+ * block_size 16 / 32.  With GQA the tile rows are (token, q head of the group) pairs, so a
+ * decode token streams its K / V once per group; no split over the keys (the
+ * paged_attention_* ops above remain the fastest decode path). */
 int vllm_amd_unified_attention(
     void* out, const void* q, const void* k_cache, const void* v_cache,
     const int* cu_seqlens_q, const int* seqused_k, const int* block_table,
@@ -337,7 +337,7 @@ int vllm_amd_unified_attention(
 /*                 11 = weight-streaming kernel (M <= 32 only),                 */
 /*                 12, 13 = 32x128 tile (1 / 2 K blocks per barrier)            */
 /*   "pf_rows":    query rows per workgroup of the prefill kernels (0 = default,    */
-/*                 64 / 128); 1 = unified_attention decode without GQA packing   */
+/*                 64 / 128); 1 = unified_attention without GQA packing          */
 /*   "cache_runs": 0 = reshape_and_cache always per token (no run detection)    */
 /*   "mm_splitk":  K slices per output tile of the direct-to-LDS kernels        */
 /*                 (0 = heuristic, 1 = never split, n = n slices; reduced       */

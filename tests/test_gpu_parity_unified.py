@@ -102,6 +102,18 @@ def test_unified_decode_batches(oracle, heads, D, fp8, mode):
         softcap=20.0 if mode == "softcap" else 0.0)
 
 
+@pytest.mark.parametrize("heads", [(8, 2), (32, 8), (6, 2), (14, 2), (16, 1)])
+@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("mode", ["plain", "window", "alibi"])
+def test_unified_mixed_batch_packed(oracle, heads, D, mode):
+    """Prefill chunks and decode tokens in one call, GQA groups that do and do not divide the
+    tile's 64 / 128 rows (6, 7): rows are (token, head) pairs, blocks of 64 // group tokens."""
+    c = make_unified_case([(1, 500), (70, 70), (1, 64), (33, 200), (9, 9), (150, 1100), (1, 1)],
+                          heads[0], heads[1], D, 16, torch.float16, seed=heads[0] * 3 + D)
+    slopes = 2.0 ** -(torch.arange(heads[0]).float() * 0.25 + 1) if mode == "alibi" else None
+    run(oracle, c, torch.float16, alibi=slopes, window=40 if mode == "window" else None)
+
+
 def test_unified_decode_packed_equals_unpacked(oracle):
     """Same decode batch through the packed and the per-head launch ("pf_rows" = 1)."""
     from vllm_amd import _lib

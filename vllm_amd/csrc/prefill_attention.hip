@@ -59,10 +59,11 @@ __device__ __forceinline__ uint2 lds_read_tr16(const uint8_t* p) {
 // FLASH layout [block][slot][kv head][d] -- and the causal bound is position-based
 // (key n visible to query m iff n <= ctx + m).  Every KV tile is staged like the new tokens of
 // the prefix kernel (K and V row-major, V read with the transposing LDS load).
-// PACK (with UNI, decode-only batches: every sequence has ONE query token): the rows of the
-// query tile are the q heads of one kv head's GQA group instead of the tokens of one head
-// (the reference packs BLOCK_M / num_queries_per_kv tokens x the group, :612-613), so the
-// group's K / V are streamed once; grid.y = kv heads.
+// PACK (with UNI): the rows of a workgroup's query tile are (token, q head of ONE kv head's GQA
+// group) pairs, token-major -- PF_BM / group tokens x the group, as the reference packs
+// BLOCK_M / num_queries_per_kv tokens (:612-613) -- instead of PF_BM tokens of one head;
+// grid.y = kv heads.  A decode token then streams its K / V once for the whole group (in a
+// batch that mixes prefill chunks and decodes, too).
 template <typename T, bool FP8, int D, int BS, int MT, int NW, bool UNI = false, bool PACK = false>
 __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams p) {
   static_assert(!PACK || UNI, "");
@@ -108,17 +109,21 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   const int gqa = p.num_heads / p.num_kv_heads;
   const int head = (wg / gridDim.x) % gridDim.y, seq = wg / (gridDim.x * gridDim.y);
   const int kvh = PACK ? head : head / gqa;
-  // tile row m -> (query token within the sequence's new tokens, q head, is it a real row)
-  auto row_tok = [&](int m) { return PACK ? 0 : m; };
-  auto row_head = [&](int m) { return PACK ? kvh * gqa + (m < gqa ? m : 0) : head; };
+  const int tpb = PACK ? PF_BM / gqa : PF_BM;   // query tokens per workgroup
+  // global row id m = start_m PF_BM + local row -> (query token within the sequence's new
+  // tokens, q head); PACK: local row = token-major (token, head in group)
+  auto row_tok = [&](int m) { return PACK ? start_m * tpb + (m - start_m * PF_BM) / gqa : m; };
+  auto row_head = [&](int m) { return PACK ? kvh * gqa + (m - start_m * PF_BM) % gqa : head; };
 
   const int seq_len = p.b_seq_len[seq];
   const int tok0 = p.b_start_loc[seq];
   const int qlen = p.b_start_loc[seq + 1] - tok0;
   const int ctx = seq_len - qlen;
   if (p.skip_decode && qlen == 1) return;
-  if (start_m * PF_BM >= qlen) return;   // the reference computes and stores nothing here
-  auto row_valid = [&](int m) { return PACK ? m < gqa : m < qlen; };
+  if (start_m * tpb >= qlen) return;   // the reference computes and stores nothing here
+  auto row_valid = [&](int m) {
+    return PACK ? (m - start_m * PF_BM < tpb * gqa && row_tok(m) < qlen) : m < qlen;
+  };
 
   const bool alibi = p.alibi_slopes != nullptr;
   const float slope2 = (alibi && !PACK) ? p.alibi_slopes[head] * kLog2e : 0.f;
@@ -132,17 +137,24 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
 
   // ---- Q^T fragments: column m = c16 of the wave's tile mt, k = d = 32 ks + 8 g4 + j ------
   const int m_wave = start_m * PF_BM + 16 * MT * wave;
+  int rtok[MT];    // this lane's rows: query token ...
+  bool rok[MT];    // ... and whether the row is real
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    rtok[mt] = row_tok(m_wave + 16 * mt + c16);
+    rok[mt] = row_valid(m_wave + 16 * mt + c16);
+  }
   uint4 qf[MT][QK_STEPS];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m_wave + 16 * mt + c16;
-    const T* qp = (const T*)p.q + (int64_t)(tok0 + (row_valid(m) ? row_tok(m) : 0)) * p.q_stride_t +
+    const T* qp = (const T*)p.q + (int64_t)(tok0 + (rok[mt] ? rtok[mt] : 0)) * p.q_stride_t +
                   (int64_t)row_head(m) * p.q_stride_h;
 #pragma unroll
     for (int ks = 0; ks < QK_STEPS; ++ks) {
       const int d0 = 32 * ks + 8 * g4;
       const uint4 v = *reinterpret_cast<const uint4*>(qp + (d0 < dr ? d0 : 0));
-      qf[mt][ks] = (row_valid(m) && d0 < dr) ? v : make_uint4(0, 0, 0, 0);
+      qf[mt][ks] = (rok[mt] && d0 < dr) ? v : make_uint4(0, 0, 0, 0);
     }
   }
 
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
     for (int i = 0; i < DT; ++i) o[i][mt] = (f32x4){0, 0, 0, 0};
   }
 
-  const int new_end = PACK ? 1 : min((start_m + 1) * PF_BM, qlen);   // causal bound of this row block
+  const int new_end = min((start_m + 1) * tpb, qlen);   // causal bound of this row block
   // UNI: no context tiles in the prefix kernel's sense; tiles cover keys [0, ctx + new_end)
   const int ctx_tiles = UNI ? 0 : (ctx + PF_BN - 1) / PF_BN;
   const int new_tiles = ((UNI ? ctx + new_end : new_end) + PF_BN - 1) / PF_BN;
@@ -450,8 +462,8 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
                 const float e2 = fast_exp2(-2.0f * kLog2e * fabsf(y));
                 x = copysignf(softcap * kLog2e * (1.0f - e2) / (1.0f + e2), y);
               }
-              bool valid = n <= ctx + row_tok(m) && row_valid(m);
-              if (window > 0 && ctx + row_tok(m) - n >= window) valid = false;
+              bool valid = n <= ctx + rtok[mt] && rok[mt];
+              if (window > 0 && ctx + rtok[mt] - n >= window) valid = false;
               if (alibi) x += (float)(n - ctx) * (PACK ? slope_row[mt] : slope2);
               x = valid ? x : -INFINITY;
               s[nt][mt][r] = x;
@@ -547,8 +559,10 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   auto tile_kind = [&](int t) {
     if constexpr (UNI) {
       const int n0 = t * PF_BN;
-      if (PACK && m_wave >= gqa) return 0;          // this wave has no q head: it only stages
-      const int p_lo = PACK ? 0 : m_wave, p_hi = PACK ? 0 : m_hi;   // query positions - ctx
+      // query tokens of the wave's first and last real row
+      const int p_lo = row_tok(m_wave);
+      const int p_hi = min(min(row_tok(m_hi), start_m * tpb + tpb - 1), qlen - 1);
+      if (PACK && (p_lo >= qlen || m_wave - start_m * PF_BM >= tpb * gqa)) return 0;   // no real row: the wave only stages
       if (n0 > ctx + p_hi) return 0;                                       // above the diagonal
       if (window > 0 && n0 + PF_BN - 1 < ctx + p_lo - window + 1) return 0;   // left of the window
       if (alibi || softcap > 0.f) return 2;
@@ -593,10 +607,10 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const int m = m_wave + 16 * mt + c16;
-    if (!row_valid(m)) continue;
+    if (!rok[mt]) continue;
     const float inv = l > 0.f ? 1.0f / l : 0.f;   // acc / l_i (:276); a fully masked row gives 0
     if (!fp8_out) {
-      T* op = (T*)p.o + (int64_t)(tok0 + row_tok(m)) * p.o_stride_t + (int64_t)row_head(m) * p.o_stride_h;
+      T* op = (T*)p.o + (int64_t)(tok0 + rtok[mt]) * p.o_stride_t + (int64_t)row_head(m) * p.o_stride_h;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         if (16 * dt + 4 * g4 >= dr) continue;
@@ -606,7 +620,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
       }
     } else {
       // acc / out_scale, clamp to the fp8 range, store e4m3 (:282-287)
-      uint8_t* op = (uint8_t*)p.o + (int64_t)(tok0 + row_tok(m)) * p.o_stride_t +
+      uint8_t* op = (uint8_t*)p.o + (int64_t)(tok0 + rtok[mt]) * p.o_stride_t +
                     (int64_t)row_head(m) * p.o_stride_h;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
@@ -635,11 +649,18 @@ static void launch_cfg(const PrefillParams& p, int block_size, int max_input_len
 template <typename T, bool FP8>
 static void launch_unified(const PrefillParams& p, int head_size, int block_size, int max_q,
                            int num_heads, int batch, hipStream_t st) {
-  // decode-only batch: rows = the GQA group's q heads (grid.y = kv heads), if the group fits
+  // GQA: rows = (token, q head of the group) pairs, grid.y = kv heads ("pf_rows" = 1: off)
   const int gqa = p.num_heads / p.num_kv_heads;
-  if (max_q == 1 && gqa > 1 && gqa <= 64 && g_pf_rows != 1) {
-    if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true, true>(p, block_size, 1, p.num_kv_heads, batch, st);
-    else launch_cfg<T, FP8, 128, 1, 4, true, true>(p, block_size, 1, p.num_kv_heads, batch, st);
+  if (gqa > 1 && gqa <= 16 && g_pf_rows != 1) {
+    if (head_size <= 64) {
+      const int tpb = 128 / gqa;   // tokens per workgroup; launch_cfg wants rows
+      launch_cfg<T, FP8, 64, 2, 4, true, true>(p, block_size, (max_q + tpb - 1) / tpb * 128,
+                                               p.num_kv_heads, batch, st);
+    } else {
+      const int tpb = 64 / gqa;
+      launch_cfg<T, FP8, 128, 1, 4, true, true>(p, block_size, (max_q + tpb - 1) / tpb * 64,
+                                                p.num_kv_heads, batch, st);
+    }
     return;
   }
   if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true>(p, block_size, max_q, num_heads, batch, st);
