@@ -310,8 +310,13 @@ int vllm_amd_context_attention_fwd(
  * Supported here: f16 / bf16 queries (no fp8 queries: q_descale is "not supported" in the
  * reference either, :609), head_size a multiple of 8 (16 with an fp8 cache) up to 128,
  * block_size 16 / 32.  With GQA the tile rows are (token, q head of the group) pairs, so a
- * decode token streams its K / V once per group; no split over the keys (the
- * paged_attention_* ops above remain the fastest decode path). */
+ * decode token streams its K / V once per group.
+ *   segm_output float [num_tokens, num_heads, num_segments, head_size], segm_max / segm_expsum
+ *            float [num_tokens, num_heads, num_segments]: caller-allocated scratch as in the
+ *            reference's 3-D path (:659-683; NUM_SEGMENTS = 16 there), or NULL / num_segments
+ *            <= 1.  When given and every sequence fits one row block (decode), the keys of a
+ *            sequence are split over up to num_segments workgroups and merged by a second
+ *            kernel (reduce_segments, :499-586); contents afterwards are unspecified. */
 int vllm_amd_unified_attention(
     void* out, const void* q, const void* k_cache, const void* v_cache,
     const int* cu_seqlens_q, const int* seqused_k, const int* block_table,
@@ -321,7 +326,8 @@ int vllm_amd_unified_attention(
     int64_t q_stride_h, int64_t o_stride_t, int64_t o_stride_h, int64_t kc_stride_block,
     int64_t kc_stride_slot, int64_t kc_stride_head, int64_t vc_stride_block,
     int64_t vc_stride_slot, int64_t vc_stride_head, float softmax_scale, int sliding_window,
-    float softcap, int dtype, int kv_cache_dtype, void* stream);
+    float softcap, int num_tokens, int max_seqlen_k, float* segm_output, float* segm_max,
+    float* segm_expsum, int num_segments, int dtype, int kv_cache_dtype, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Tuning knobs (no counterpart in the reference): used by tools/ and bench   */

@@ -174,13 +174,14 @@ def test_validation_errors_of_the_neighbour_ops():
 
     # unified attention (flash-layout cache)
     def ua(head_size=128, block_size=16, dtype=_lib.BF16, kv=_lib.KV_AUTO, heads=8, kvh=2, seqs=1,
-           qs=1024, window=0, softcap=0.0, kd=p):
+           qs=1024, window=0, softcap=0.0, kd=p, nseg=0):
         return L.vllm_amd_unified_attention(
             p, p, p, p, p, p, p, kd, kd, None, None, seqs, heads, kvh, head_size, block_size, 64,
             16, qs, head_size, heads * head_size, head_size, block_size * kvh * head_size,
             kvh * head_size, head_size, block_size * kvh * head_size, kvh * head_size, head_size,
-            0.1, window, softcap, dtype, kv, None)
+            0.1, window, softcap, 64, 4096, None, None, None, nseg, dtype, kv, None)
     assert ua(seqs=0) == 0
+    assert "segment buffers" in _err(ua(nseg=16))
     assert "unsupported head size: 256" in _err(ua(head_size=256))
     assert "unsupported head size: 40" in _err(ua(head_size=40, kv=_lib.KV_FP8_E4M3, qs=320))
     assert "unsupported block size: 64" in _err(ua(block_size=64))

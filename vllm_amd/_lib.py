@@ -55,7 +55,8 @@ SIGNATURES = {
         _i, _i, _vp],
     "vllm_amd_unified_attention": [
         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
-        _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _f, _i, _i, _vp],
+        _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _f, _i, _i, _vp,
+        _vp, _vp, _i, _i, _i, _vp],
     "vllm_amd_set_tuning": [C.c_char_p, _i],
 }
 

@@ -41,6 +41,17 @@ def unified_attention(q, k, v, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_s
         assert out.dtype in _FP8
     else:
         assert out.dtype == q.dtype
+    # few decode sequences: scratch for the split over the keys, allocated here as the
+    # reference does for its 3-D kernel (:659-683, NUM_SEGMENTS = 16)
+    segm_out = segm_max = segm_sum = None
+    nseg = 0
+    num_kv_heads = k.shape[2]
+    if max_seqlen_q == 1 and num_seqs * num_kv_heads < 512 and q.shape[1] > num_kv_heads:
+        nseg = 16
+        segm_out = torch.empty((q.shape[0], q.shape[1], nseg, q.shape[2]), dtype=torch.float32,
+                               device=q.device)
+        segm_max = torch.empty((q.shape[0], q.shape[1], nseg), dtype=torch.float32, device=q.device)
+        segm_sum = torch.empty_like(segm_max)
     with _dev(q):
         check(lib.vllm_amd_unified_attention(
             _ptr(out), _ptr(q), _ptr(k), _ptr(v), _ptr(cu_seqlens_q), _ptr(seqused_k),
@@ -49,4 +60,5 @@ def unified_attention(q, k, v, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_s
             int(max_seqlen_q), block_table.stride(0), q.stride(0), q.stride(1), out.stride(0),
             out.stride(1), k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1),
             v.stride(2), float(softmax_scale), 1 + int(window_size[0]), float(softcap or 0.0),
+            q.shape[0], int(max_seqlen_k), _ptr(segm_out), _ptr(segm_max), _ptr(segm_sum), nseg,
             _DT[q.dtype], _lib.KV_FP8_E4M3 if fp8 else _lib.KV_AUTO, _stream(q)))

@@ -40,6 +40,10 @@ struct PrefillParams {
   // unified_attention only (UNI): flash-layout cache [block][slot][head][d], softcap
   int64_t kc_page_bytes, vc_page_bytes;
   float softcap;
+  // split over the keys (PACK launches with one row block): segment partials, caller-allocated
+  float* segm_out; float* segm_max; float* segm_sum;
+  int num_segments;     // segments of this launch (1 = no split)
+  int segm_stride;      // segments the buffers were allocated for
 };
 
 // transposing 8-byte LDS read (4 x 16 bit), see compute_tile
@@ -105,7 +109,10 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
     wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
-  const int start_m = gridDim.x - 1 - wg % gridDim.x;
+  // split launches (PACK, one row block per sequence): blockIdx.x is the key segment
+  const bool split = PACK && p.num_segments > 1;
+  const int seg = split ? wg % gridDim.x : 0;
+  const int start_m = split ? 0 : gridDim.x - 1 - wg % gridDim.x;
   const int gqa = p.num_heads / p.num_kv_heads;
   const int head = (wg / gridDim.x) % gridDim.y, seq = wg / (gridDim.x * gridDim.y);
   const int kvh = PACK ? head : head / gqa;
@@ -582,14 +589,20 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   };
 
   // ---- pipeline: the next tile's global loads fly under the MFMAs of the current one ---------------
-  Pages pages = load_pages(0);
-  if (ntiles > 0) load_tile(0, pages);
-  pages = load_pages(1);
-  for (int t = 0; t < ntiles; ++t) {
+  // (split: this workgroup takes tiles [t_begin, t_end) -- the reference's
+  // tiles_per_segment = cdiv(seq_len, NUM_SEGMENTS * BLOCK_SIZE), :388-396 -- and leaves
+  // unnormalised partials for unified_reduce_kernel; a segment past the sequence writes nothing)
+  const int tps = split ? (ntiles + p.num_segments - 1) / p.num_segments : ntiles;
+  const int t_begin = seg * tps, t_end = min(t_begin + tps, ntiles);
+  if (split && t_begin >= ntiles) return;
+  Pages pages = load_pages(t_begin);
+  if (t_end > t_begin) load_tile(t_begin, pages);
+  pages = load_pages(t_begin + 1);
+  for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();          // everyone is done reading the previous tile
     store_tile(t);
     __syncthreads();
-    if (t + 1 < ntiles) {
+    if (t + 1 < t_end) {
       load_tile(t + 1, pages);
       pages = load_pages(t + 2);
     }
@@ -608,6 +621,19 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
     l += __shfl_xor(l, 32, 64);
     const int m = m_wave + 16 * mt + c16;
     if (!rok[mt]) continue;
+    if (split) {
+      // partial of this segment: O (unnormalised, fp32), running max (log2 domain), sum
+      const int64_t row = ((int64_t)(tok0 + rtok[mt]) * p.num_heads + row_head(m)) * p.segm_stride + seg;
+      float* so = p.segm_out + row * dr;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        if (16 * dt + 4 * g4 < dr) *reinterpret_cast<f32x4*>(so + 16 * dt + 4 * g4) = o[dt][mt];
+      if (g4 == 0) {
+        p.segm_max[row] = m_run[mt];
+        p.segm_sum[row] = l;
+      }
+      continue;
+    }
     const float inv = l > 0.f ? 1.0f / l : 0.f;   // acc / l_i (:276); a fully masked row gives 0
     if (!fp8_out) {
       T* op = (T*)p.o + (int64_t)(tok0 + rtok[mt]) * p.o_stride_t + (int64_t)row_head(m) * p.o_stride_h;
@@ -635,6 +661,53 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   }
 }
 
+// Merge of the key segments (reduce_segments, triton_unified_attention.py:499-586): one wave per
+// (token, q head); segment s of a sequence exists iff s * tiles_per_segment < its tiles.
+template <typename T>
+__global__ __launch_bounds__(64) void unified_reduce_kernel(const PrefillParams p, int rows_per_block,
+                                                            int num_seqs) {
+  const int tok = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
+  // sequence of this token: last seq with cu_seqlens_q[seq] <= tok (find_seq_idx, :33-48)
+  int seq = 0;
+  for (int lo = 0, hi = num_seqs; lo < hi;) {
+    const int mid = (lo + hi) >> 1;
+    if (p.b_start_loc[mid] <= tok) { seq = mid; lo = mid + 1; } else hi = mid;
+  }
+  const int seq_len = p.b_seq_len[seq];
+  const int qlen = p.b_start_loc[seq + 1] - p.b_start_loc[seq];
+  const int kv_end = min(seq_len - qlen + min(rows_per_block, qlen), seq_len);
+  const int ntiles = (kv_end + PF_BN - 1) / PF_BN;
+  const int tps = (ntiles + p.num_segments - 1) / p.num_segments;
+  const int nseg = tps > 0 ? (ntiles + tps - 1) / tps : 0;
+  const int64_t row = ((int64_t)tok * p.num_heads + head) * p.segm_stride;
+  float mx = -INFINITY;
+  for (int s2 = 0; s2 < nseg; ++s2) mx = fmaxf(mx, p.segm_max[row + s2]);
+  const int dr = p.head_size;
+  float acc[2] = {0.f, 0.f}, l = 0.f;
+  for (int s2 = 0; s2 < nseg; ++s2) {
+    const float ms = p.segm_max[row + s2];
+    const float w = ms == -INFINITY ? 0.f : fast_exp2(ms - mx);
+    l += p.segm_sum[row + s2] * w;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int d = lane + 64 * j;
+      if (d < dr) acc[j] += p.segm_out[(row + s2) * dr + d] * w;
+    }
+  }
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int d = lane + 64 * j;
+    if (d >= dr) continue;
+    if (p.fp8_out_scale) {
+      const float y = fmaxf(-448.0f, fminf(acc[j] * inv * (1.0f / *p.fp8_out_scale), 448.0f));
+      ((uint8_t*)p.o)[(int64_t)tok * p.o_stride_t + (int64_t)head * p.o_stride_h + d] = f32_to_fp8(y);
+    } else {
+      ((T*)p.o)[(int64_t)tok * p.o_stride_t + (int64_t)head * p.o_stride_h + d] = from_f32<T>(acc[j] * inv);
+    }
+  }
+}
+
 template <typename T, bool FP8, int D, int MT, int NW, bool UNI = false, bool PACK = false>
 static void launch_cfg(const PrefillParams& p, int block_size, int max_input_len, int num_heads,
                        int batch, hipStream_t st) {
@@ -647,22 +720,34 @@ static void launch_cfg(const PrefillParams& p, int block_size, int max_input_len
 }
 // unified_attention: padded head sizes 64 and 128 (one configuration each)
 template <typename T, bool FP8>
-static void launch_unified(const PrefillParams& p, int head_size, int block_size, int max_q,
-                           int num_heads, int batch, hipStream_t st) {
+static void launch_unified(PrefillParams p, int head_size, int block_size, int max_q, int max_k,
+                           int num_tokens, int num_heads, int batch, hipStream_t st) {
   // GQA: rows = (token, q head of the group) pairs, grid.y = kv heads ("pf_rows" = 1: off)
   const int gqa = p.num_heads / p.num_kv_heads;
   if (gqa > 1 && gqa <= 16 && g_pf_rows != 1) {
-    if (head_size <= 64) {
-      const int tpb = 128 / gqa;   // tokens per workgroup; launch_cfg wants rows
-      launch_cfg<T, FP8, 64, 2, 4, true, true>(p, block_size, (max_q + tpb - 1) / tpb * 128,
-                                               p.num_kv_heads, batch, st);
+    const int bm = head_size <= 64 ? 128 : 64;   // rows per workgroup
+    const int tpb = bm / gqa;                     // tokens per workgroup
+    int rows = (max_q + tpb - 1) / tpb * bm;      // launch_cfg wants rows: grid.x = rows / bm
+    // few sequences of one row block each (decode): split the keys over up to num_segments
+    // workgroups so that the launch has ~512 of them, >= 4 tiles per segment
+    if (p.num_segments > 1 && max_q <= tpb) {
+      int nseg = (512 + batch * p.num_kv_heads - 1) / (batch * p.num_kv_heads);
+      const int by_len = (max_k + 4 * PF_BN - 1) / (4 * PF_BN);
+      if (nseg > by_len) nseg = by_len;
+      if (nseg > p.num_segments) nseg = p.num_segments;
+      p.num_segments = nseg > 1 ? nseg : 1;
+      rows = p.num_segments * bm;
     } else {
-      const int tpb = 64 / gqa;
-      launch_cfg<T, FP8, 128, 1, 4, true, true>(p, block_size, (max_q + tpb - 1) / tpb * 64,
-                                                p.num_kv_heads, batch, st);
+      p.num_segments = 1;
     }
+    if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true, true>(p, block_size, rows, p.num_kv_heads, batch, st);
+    else launch_cfg<T, FP8, 128, 1, 4, true, true>(p, block_size, rows, p.num_kv_heads, batch, st);
+    if (p.num_segments > 1)
+      hipLaunchKernelGGL((unified_reduce_kernel<T>), dim3(num_tokens, num_heads), dim3(64), 0, st, p, tpb,
+                         batch);
     return;
   }
+  p.num_segments = 1;
   if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true>(p, block_size, max_q, num_heads, batch, st);
   else launch_cfg<T, FP8, 128, 1, 4, true>(p, block_size, max_q, num_heads, batch, st);
 }
@@ -751,6 +836,8 @@ extern "C" int vllm_amd_context_attention_fwd(
   p.skip_decode = skip_decode;
   p.kc_page_bytes = p.vc_page_bytes = 0;
   p.softcap = 0.f;
+  p.segm_out = p.segm_max = p.segm_sum = nullptr;
+  p.num_segments = p.segm_stride = 1;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VLLM_AMD_BF16) {
     if (es == 2) launch_d<bf16_t, false>(p, head_size, block_size, max_input_len, num_heads, batch, st);
@@ -773,7 +860,9 @@ extern "C" int vllm_amd_unified_attention(
     int64_t q_stride_t, int64_t q_stride_h, int64_t o_stride_t, int64_t o_stride_h,
     int64_t kc_stride_block, int64_t kc_stride_slot, int64_t kc_stride_head,
     int64_t vc_stride_block, int64_t vc_stride_slot, int64_t vc_stride_head, float softmax_scale,
-    int sliding_window, float softcap, int dtype, int kv_cache_dtype, void* stream) {
+    int sliding_window, float softcap, int num_tokens, int max_seqlen_k, float* segm_output,
+    float* segm_max, float* segm_expsum, int num_segments, int dtype, int kv_cache_dtype,
+    void* stream) {
   const char* op = "unified_attention";
   VA_REQUIRE(num_seqs >= 0 && max_seqlen_q >= 0, VLLM_AMD_EINVAL, "%s: negative size", op);
   if (num_seqs == 0 || max_seqlen_q == 0 || num_heads == 0) return VLLM_AMD_OK;
@@ -796,6 +885,9 @@ extern "C" int vllm_amd_unified_attention(
              "%s: fp8 cache needs k_descale and v_descale", op);
   VA_REQUIRE(softcap >= 0.f && sliding_window >= 0, VLLM_AMD_EINVAL,
              "%s: softcap and sliding_window must not be negative", op);
+  VA_REQUIRE(num_segments <= 1 || (segm_output && segm_max && segm_expsum && num_tokens > 0 &&
+                                   (((uintptr_t)segm_output) & 15) == 0),
+             VLLM_AMD_EINVAL, "%s: num_segments > 1 needs the three segment buffers (16-byte aligned) and num_tokens", op);
   const int ca = 16 / es;   // cache elements per 16 bytes
   VA_REQUIRE(q_stride_t % 8 == 0 && q_stride_h % 8 == 0 && o_stride_t % 4 == 0 &&
                  o_stride_h % 4 == 0 && kc_stride_block % ca == 0 && kc_stride_slot % ca == 0 &&
@@ -824,13 +916,16 @@ extern "C" int vllm_amd_unified_attention(
   p.sliding_window = sliding_window;
   p.skip_decode = 0;
   p.softcap = softcap;
+  p.segm_out = segm_output; p.segm_max = segm_max; p.segm_sum = segm_expsum;
+  p.num_segments = num_segments > 1 ? num_segments : 1;
+  p.segm_stride = p.num_segments;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VLLM_AMD_BF16) {
-    if (es == 2) launch_unified<bf16_t, false>(p, head_size, block_size, max_seqlen_q, num_heads, num_seqs, st);
-    else launch_unified<bf16_t, true>(p, head_size, block_size, max_seqlen_q, num_heads, num_seqs, st);
+    if (es == 2) launch_unified<bf16_t, false>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);
+    else launch_unified<bf16_t, true>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);
   } else {
-    if (es == 2) launch_unified<f16_t, false>(p, head_size, block_size, max_seqlen_q, num_heads, num_seqs, st);
-    else launch_unified<f16_t, true>(p, head_size, block_size, max_seqlen_q, num_heads, num_seqs, st);
+    if (es == 2) launch_unified<f16_t, false>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);
+    else launch_unified<f16_t, true>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);
   }
   VA_LAUNCH_CHECK(op);
   return VLLM_AMD_OK;
