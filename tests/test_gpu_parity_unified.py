@@ -93,13 +93,20 @@ def test_unified_alibi(oracle, window):
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("mode", ["plain", "window", "alibi", "softcap"])
 def test_unified_decode_batches(oracle, heads, D, fp8, mode):
-    """Decode-only batches (every query length 1) take the GQA-packed launch: tile rows = the
-    q heads of a kv head's group.  Lengths around the 64-key tile and the page size."""
+    """Decode-only batches (every query length 1): the decode kernel and the GQA-packed tile
+    launch (tile rows = the q heads of a kv head's group).  Lengths around the 64-key tile and
+    the page size."""
     c = make_unified_case([(1, 1), (1, 64), (1, 65), (1, 300), (1, 17), (1, 1000)], heads[0], heads[1],
                           D, 16, torch.bfloat16, fp8=fp8, seed=heads[0] + D, kv_scale=0.5)
     slopes = 2.0 ** -(torch.arange(heads[0]).float() * 0.25 + 1) if mode == "alibi" else None
-    run(oracle, c, torch.bfloat16, fp8=fp8, alibi=slopes, window=48 if mode == "window" else None,
-        softcap=20.0 if mode == "softcap" else 0.0)
+    from vllm_amd import _lib
+    try:
+        for knob in (1, 0):   # the decode kernel, then the packed tile kernel
+            _lib.set_tuning("uni_decode", knob)
+            run(oracle, c, torch.bfloat16, fp8=fp8, alibi=slopes, window=48 if mode == "window" else None,
+                softcap=20.0 if mode == "softcap" else 0.0)
+    finally:
+        _lib.set_tuning("uni_decode", 1)
 
 
 @pytest.mark.parametrize("heads", [(8, 2), (32, 8), (6, 2), (14, 2), (16, 1)])
@@ -112,6 +119,57 @@ def test_unified_mixed_batch_packed(oracle, heads, D, mode):
                           heads[0], heads[1], D, 16, torch.float16, seed=heads[0] * 3 + D)
     slopes = 2.0 ** -(torch.arange(heads[0]).float() * 0.25 + 1) if mode == "alibi" else None
     run(oracle, c, torch.float16, alibi=slopes, window=40 if mode == "window" else None)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("block_size", [16, 32])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("nseq", [3, 140])
+def test_unified_decode_kernel(oracle, dtype, block_size, fp8, nseq):
+    """The flash-layout decode kernel (unified_decode.hip): split over key segments (few
+    sequences) and unsplit (>= 512 workgroups), both block sizes and dtypes, lengths around the
+    step (32 / 64 tokens), the page and the 64-token segment tile."""
+    lens = [1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 257, 700, 1, 16, 17]
+    seqs = [(1, lens[i % len(lens)] + (i // len(lens))) for i in range(nseq)]
+    if nseq == 3:
+        seqs = [(1, 2500), (1, 64), (1, 1023)]
+    c = make_unified_case(seqs, 8, 4, 128, block_size, dtype, fp8=fp8, seed=nseq + block_size, kv_scale=0.5)
+    run(oracle, c, dtype, fp8=fp8)
+
+
+@pytest.mark.parametrize("mode", ["window", "alibi", "softcap", "fp8_out", "hnd"])
+@pytest.mark.parametrize("fp8", [False, True])
+def test_unified_decode_kernel_features(oracle, mode, fp8):
+    """Window edges inside / across steps and segments, ALiBi, softcap, fp8 output and a
+    head-major (HND) cache allocation, unsplit launch (520 workgroups)."""
+    lens = [5, 100, 129, 300, 640, 1000]
+    seqs = [(1, lens[i % len(lens)] + i // 6) for i in range(130)]
+    c = make_unified_case(seqs, 8, 4, 64 if mode == "alibi" else 128, 16, torch.bfloat16, fp8=fp8, seed=77,
+                          kv_scale=0.5)
+    slopes = 2.0 ** -(torch.arange(8).float() * 0.25 + 1) if mode == "alibi" else None
+    view = (lambda t: t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)) if mode == "hnd" else None
+    run(oracle, c, torch.bfloat16, fp8=fp8, alibi=slopes, window=100 if mode == "window" else None,
+        softcap=15.0 if mode == "softcap" else 0.0,
+        out_scale=torch.tensor([0.02]) if mode == "fp8_out" else None, view=view)
+
+
+def test_unified_decode_kernel_equals_packed(oracle):
+    """Same decode batch through the decode kernel and the packed tile kernel ("uni_decode" = 0)."""
+    from vllm_amd import _lib
+    from vllm_amd.attention.ops import unified_attention
+    c = make_unified_case([(1, 700), (1, 33), (1, 4000)], 16, 4, 128, 16, torch.bfloat16, fp8=True, seed=4,
+                          kv_scale=0.5)
+    outs = []
+    sc = c["scale"].cuda()
+    for knob in (1, 0):
+        _lib.set_tuning("uni_decode", knob)
+        out = torch.zeros(c["q"].shape, dtype=torch.bfloat16, device="cuda")
+        unified_attention(c["q"].cuda(), c["k"].cuda(), c["v"].cuda(), out, c["cu_seqlens_q"].cuda(), 1,
+                          c["seqused_k"].cuda(), 4000, 128 ** -0.5, True, (-1, -1),
+                          c["block_table"].cuda(), 0.0, None, sc, sc)
+        outs.append(out.cpu())
+    _lib.set_tuning("uni_decode", 1)
+    torch.testing.assert_close(outs[0].float(), outs[1].float(), atol=4e-3, rtol=4e-3)
 
 
 def test_unified_decode_packed_equals_unpacked(oracle):

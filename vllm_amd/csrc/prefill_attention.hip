@@ -17,6 +17,7 @@
 // scaled and rounded to the query dtype like the reference, new V is transposed), with the
 // next tile's global loads in flight during the MFMAs.
 #include "mma.cuh"
+#include "unified_decode.cuh"
 
 #include <float.h>
 #include <type_traits>
@@ -25,6 +26,7 @@ namespace va {
 
 constexpr int PF_BN = 64;
 int g_pf_rows = 0;   // tuning "pf_rows": query rows per workgroup (0 = default)
+int g_uni_decode = 1;   // tuning "uni_decode": 0 = decode-only launches take the packed tile kernel
 
 struct PrefillParams {
   void* o; const void* q; const void* k; const void* v;
@@ -722,8 +724,45 @@ static void launch_cfg(const PrefillParams& p, int block_size, int max_input_len
 template <typename T, bool FP8>
 static void launch_unified(PrefillParams p, int head_size, int block_size, int max_q, int max_k,
                            int num_tokens, int num_heads, int batch, hipStream_t st) {
-  // GQA: rows = (token, q head of the group) pairs, grid.y = kv heads ("pf_rows" = 1: off)
   const int gqa = p.num_heads / p.num_kv_heads;
+  // decode-only launch: the flash-layout bandwidth kernel (unified_decode.hip)
+  if (max_q == 1 && g_uni_decode && g_pf_rows != 1) {
+    UniDecodeParams u;
+    u.out = p.o; u.q = p.q; u.k_cache = p.k_cache; u.v_cache = p.v_cache;
+    u.cu_seqlens_q = p.b_start_loc; u.seq_lens = p.b_seq_len; u.block_table = p.b_loc;
+    u.k_scale = p.k_scale; u.v_scale = p.v_scale; u.alibi_slopes = p.alibi_slopes;
+    u.out_scale = p.fp8_out_scale;
+    u.num_seqs = batch; u.num_heads = p.num_heads; u.num_kv_heads = p.num_kv_heads;
+    u.head_size = head_size; u.block_size = block_size;
+    u.bt_stride = p.b_loc_stride; u.q_stride_t = p.q_stride_t; u.q_stride_h = p.q_stride_h;
+    u.o_stride_t = p.o_stride_t; u.o_stride_h = p.o_stride_h;
+    u.kc_block_bytes = p.kc_block_bytes; u.kc_slot_bytes = p.kc_page_bytes; u.kc_head_bytes = p.kc_head_bytes;
+    u.vc_block_bytes = p.vc_block_bytes; u.vc_slot_bytes = p.vc_page_bytes; u.vc_head_bytes = p.vc_head_bytes;
+    u.sm_scale = p.sm_scale; u.softcap = p.softcap; u.window = p.sliding_window;
+    u.segm_out = p.segm_out; u.segm_max = p.segm_max; u.segm_sum = p.segm_sum;
+    u.segm_stride = p.segm_stride;
+    u.dtype = std::is_same<T, f16_t>::value ? VLLM_AMD_F16 : VLLM_AMD_BF16;
+    u.fp8 = FP8; u.stream = st;
+    // few sequences: split the keys so that the launch has ~512 workgroups of >= 256 tokens
+    int nseg = 1;
+    if (p.num_segments > 1) {
+      nseg = (512 + batch * p.num_kv_heads - 1) / (batch * p.num_kv_heads);
+      const int by_len = (max_k + 4 * PF_BN - 1) / (4 * PF_BN);
+      if (nseg > by_len) nseg = by_len;
+      if (nseg > p.num_segments) nseg = p.num_segments;
+      if (nseg < 1) nseg = 1;
+    }
+    u.num_segments = nseg;
+    if (unified_decode_supported(u)) {
+      if (unified_decode(u) != VLLM_AMD_OK) return;
+      if (nseg > 1) {
+        p.num_segments = nseg;
+        hipLaunchKernelGGL((unified_reduce_kernel<T>), dim3(num_tokens, num_heads), dim3(64), 0, st, p, 1, batch);
+      }
+      return;
+    }
+  }
+  // GQA: rows = (token, q head of the group) pairs, grid.y = kv heads ("pf_rows" = 1: off)
   if (gqa > 1 && gqa <= 16 && g_pf_rows != 1) {
     const int bm = head_size <= 64 ? 128 : 64;   // rows per workgroup
     const int tpb = bm / gqa;                     // tokens per workgroup

@@ -1,0 +1,32 @@
+// Internal interface: decode-only launches of unified_attention (unified_decode.hip).
+#pragma once
+#include "common.cuh"
+
+namespace va {
+
+struct UniDecodeParams {
+  void* out; const void* q;
+  const uint8_t* k_cache; const uint8_t* v_cache;       // flash layout [block][slot][kv head][d]
+  const int* cu_seqlens_q; const int* seq_lens; const int* block_table;
+  const float* k_scale; const float* v_scale; const float* alibi_slopes; const float* out_scale;
+  int num_seqs, num_heads, num_kv_heads, head_size, block_size;
+  int64_t bt_stride, q_stride_t, q_stride_h, o_stride_t, o_stride_h;   // elements
+  int64_t kc_block_bytes, kc_slot_bytes, kc_head_bytes, vc_block_bytes, vc_slot_bytes, vc_head_bytes;
+  float sm_scale, softcap;
+  int window;            // 0 = none; key n visible iff seq_len - 1 - n < window
+  // split over the keys: segment s takes the 64-token tiles [s tps, (s+1) tps), tps =
+  // cdiv(cdiv(seq_len, 64), num_segments) -- the partition unified_reduce_kernel assumes
+  float* segm_out; float* segm_max; float* segm_sum;
+  int num_segments, segm_stride;
+  int dtype;             // VLLM_AMD_F16 / VLLM_AMD_BF16
+  bool fp8;              // e4m3 cache
+  hipStream_t stream;
+};
+
+// true when every query of the launch may take the decode kernel (the caller has checked
+// max_seqlen_q == 1); false WITHOUT touching memory otherwise
+bool unified_decode_supported(const UniDecodeParams& p);
+// main kernel only; with num_segments > 1 the caller merges the partials
+int unified_decode(const UniDecodeParams& p);
+
+}  // namespace va
