@@ -7,10 +7,13 @@
 // every K / V byte is read once.  Waves stride over steps of 16 KiB of KV (fp8: 64 tokens,
 // 16-bit: 32), each with a private online softmax; one merge through LDS at the end.
 //
-//   K  a token's row is d-contiguous -- already the A-operand order of S^T = K Q^T.  Lane
-//      (token c16, group g4) loads 16 bytes at d-chunk g4 + 4 i: per instruction the wave reads
-//      64 contiguous bytes of 16 token rows; the contraction index is permuted to that order
-//      and Q^T is loaded once in the same permutation.
+//   K  a token's row is d-contiguous -- the A-operand order of S^T = K Q^T -- but a lane of the
+//      MFMA layout is one token, and 16 lanes reading 16 bytes each of 16 different rows cost
+//      the L1 sixteen tag look-ups per 256 bytes (measured 4.5 TB/s).  So K is loaded with
+//      whole rows per 8 lanes (fp8, head 128: an instruction = 8 contiguous 128-byte rows),
+//      written to a wave-private LDS image (XOR-swizzled on the SOURCE side, so the write is
+//      the plain lane order) and read back in MFMA order, conflict-free.  The contraction
+//      index is permuted to the chunk order (g4 + 4 i) and Q^T is loaded once in the same order.
 //   V  rows are [token][d], the PV product O^T += V^T P^T wants 8 TOKENS of one d per lane.  The
 //      contraction slots of lane group g4 are tokens 16 ta + 4 g4 + [0,4) and 16 tb + 4 g4 + [0,4)
 //      of a tile pair (ta, tb) -- exactly the tokens whose probabilities the lane holds after the
@@ -21,7 +24,7 @@
 //      fp8 -> 16-bit widening (exact) then yields the packed (token, token + 1) operand dwords.
 //      MFMA j produces rows d = DT i + j (i = A row): a permutation of d undone in the merge.
 //   Addresses are a wave-uniform 64-bit base per (tile, row) plus one 32-bit lane offset per
-//   operand that never changes (SGPR base + VGPR offset loads); no LDS and no barrier in the loop.
+//   operand that never changes (SGPR base + VGPR offset loads); no workgroup barrier in the loop.
 #include "unified_decode.cuh"
 #include "mma.cuh"
 
@@ -97,8 +100,11 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   const float softcap = p.softcap;
   const float cap_inv = softcap > 0.f ? 1.0f / (kLog2e * softcap) : 0.f, cap2 = softcap * kLog2e;
 
+  constexpr int K_LDS = TILES * 16 * D * ES;   // one step of K per wave
   constexpr int MERGE_BYTES = NW * D * 16 * 4 + NW * 16 * 8;
-  __shared__ __attribute__((aligned(16))) char lds[MERGE_BYTES];
+  constexpr int LDS_BYTES = NW * K_LDS > MERGE_BYTES ? NW * K_LDS : MERGE_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  char* const k_lds = lds + wave * K_LDS;
 
   // Q^T fragments (B operand of QK) in the K loads' permutation:
   // fp8 : K load i gives d = 16 (g4 + 4 i) + [0,16) -> two k-steps (lo / hi 8); 16 bit: d = 8 (g4 + 4 i) + [0,8)
@@ -125,7 +131,18 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   int pb[TILES];            // block ids of the step whose loads are issued next
 
   // lane offsets within a tile (bytes, fixed for the whole kernel)
-  const uint32_t koff = (uint32_t)(c16 * p.kc_slot_bytes + g4 * 16);
+  // K: instruction i of a tile fetches rows i RPI .. + RPI, CPR lanes per row, each lane one
+  // 16-byte chunk; the chunk a lane fetches is XOR-swizzled so that the image it writes to LDS
+  // (lane order = [row][position]) is read back conflict-free in the MFMA order
+  constexpr int RB = D * ES, CPR = RB / 16, RPI = 64 / CPR;   // row bytes, chunks per row, rows per instruction
+  auto kswz = [](int row) { return (row * CPR / 16) & (CPR - 1); };
+  uint32_t koff[KL], krd[KL];
+#pragma unroll
+  for (int i = 0; i < KL; ++i) {
+    const int row = i * RPI + lane / CPR;
+    koff[i] = (uint32_t)(row * p.kc_slot_bytes + (((lane % CPR) ^ kswz(row)) << 4));
+    krd[i] = (uint32_t)(c16 * RB + (((g4 + 4 * i) ^ kswz(c16)) << 4));
+  }
   uint32_t voff[4];   // row r of the lane's four tokens of a tile
 #pragma unroll
   for (int r = 0; r < 4; ++r) voff[r] = (uint32_t)((4 * g4 + r) * p.vc_slot_bytes + c16 * (DT * ES));
@@ -143,14 +160,18 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   // which would turn every load into a 64-bit VGPR address + add instead of SGPR base + offset)
   auto issue_k = [&](int step) {
     const int tile0 = (start_tok >> 4) + step * TILES;
-    uint32_t ko = koff;
-    asm volatile("" : "+v"(ko));
+    uint32_t ko[KL];
+#pragma unroll
+    for (int i = 0; i < KL; ++i) {
+      ko[i] = koff[i];
+      asm volatile("" : "+v"(ko[i]));
+    }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
       const uint8_t* base = k_head + (int64_t)pb[t] * p.kc_block_bytes +
                             (int64_t)(((tile0 + t) & sub_mask) * 16) * p.kc_slot_bytes;
 #pragma unroll
-      for (int i = 0; i < KL; ++i) kreg[t * KL + i] = nt_load<4>(base + 64 * i + ko);
+      for (int i = 0; i < KL; ++i) kreg[t * KL + i] = nt_load<4>(base + ko[i]);
     }
   };
   auto issue_v = [&](int step) {
@@ -173,6 +194,12 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   auto do_step = [&](int step) {
     const int tok0 = start_tok + step * STEP_TOK;
     const int pf = step + NW;
+    // ---------------- K: registers -> wave-private LDS image -> MFMA order ----------------
+#pragma unroll
+    for (int n = 0; n < TILES * KL; ++n)
+      *reinterpret_cast<u32x4*>(k_lds + n * 1024 + lane * 16) = kreg[n];
+    const bool more = pf < nsteps;
+    if (more) issue_k(pf);
     // ---------------- S^T = K Q^T ----------------------------------------------------
     f32x4 s[TILES];
 #pragma unroll
@@ -180,7 +207,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < KL; ++i) {
-        const u32x4 kr = kreg[t * KL + i];
+        const u32x4 kr = *reinterpret_cast<const u32x4*>(k_lds + t * 16 * RB + krd[i]);
         const uint4 raw = make_uint4(kr.x, kr.y, kr.z, kr.w);
         if constexpr (FP8) {
           uint4 lo, hi;
@@ -193,8 +220,6 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
       }
       s[t] = acc;
     }
-    const bool more = pf < nsteps;
-    if (more) issue_k(pf);
 
     // ---------------- online softmax: lane holds S^T[token tok0 + 16 t + 4 g4 + r][q head c16] -------
     float mx = -FLT_MAX;
@@ -293,6 +318,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   // ---------------- merge the NW waves ----------------------------------------------------
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
+  __syncthreads();   // the K images are dead; LDS becomes the merge buffer
   float* om = reinterpret_cast<float*>(lds);   // [NW][D][16]
   float* ml = om + NW * D * 16;                 // [NW][16][2]
   if (g4 == 0) {
