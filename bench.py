@@ -298,6 +298,32 @@ def run_prefill(device, iters=5):
     return out
 
 
+def run_unified_decode(device, iters=5):
+    """Decode-only batches through unified_attention (the V1 engine's op, flash-layout fp8
+    cache, unified_decode.hip) at the configs[1] head shape; bytes = K and V read once."""
+    from vllm_amd.attention.ops import unified_attention
+    H, KVH, D, BS = 32, 8, 128, 16
+    out = {}
+    for S, ctx in ((64, 4096), (256, 4096), (16, 16384), (1, 4096)):
+        nb = (ctx + BS - 1) // BS
+        q = (torch.rand((S, H, D), device=device) - 0.5).to(torch.bfloat16)
+        o = torch.empty_like(q)
+        kf = torch.randint(0, 120, (S * nb, BS, KVH, D), device=device, dtype=torch.uint8)
+        vf = torch.randint(0, 120, (S * nb, BS, KVH, D), device=device, dtype=torch.uint8)
+        bt = torch.randperm(S * nb, device=device).to(torch.int32).view(S, nb)
+        cu = torch.arange(S + 1, device=device, dtype=torch.int32)
+        sl = torch.full((S,), ctx, dtype=torch.int32, device=device)
+        sc = torch.full((1,), 0.02, device=device)
+        fn = lambda: unified_attention(q, kf, vf, o, cu, 1, sl, ctx, D ** -0.5, True, (-1, -1), bt,
+                                       0.0, None, sc, sc)
+        t = time_gpu_graph(fn, iters)
+        nbytes = 2 * S * ctx * KVH * D + 2 * S * H * D * 2 + S * nb * 4
+        out[f"S{S}_ctx{ctx}_fp8kv"] = dict(us=round(t * 1e6, 1), gbps=round(nbytes / t / 1e9, 1),
+                                           frac_of_hbm_peak=round(nbytes / t / 1e9 / HBM_PEAK_GBPS, 4))
+        del kf, vf
+    return out
+
+
 def cpu_baseline():
     """Reference CPU paged_attention_v1 on BASELINE.json configs[0] (32 seqs, ctx 1024,
     32q/8kv, d 128, block 16, bf16 KV), all host cores available to this process."""
@@ -428,6 +454,7 @@ def main():
             extra["cache_quant"] = run_cache_quant(device)
             extra["fused_neighbours"] = run_fused_neighbours(device)
             extra["prefill_attention"] = run_prefill(device)
+            extra["unified_decode"] = run_unified_decode(device)
             line["cpu_baseline"] = cpu_baseline()
         line["extra"] = extra
     if use_dist:

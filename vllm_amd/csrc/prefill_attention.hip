@@ -722,7 +722,7 @@ static void launch_cfg(const PrefillParams& p, int block_size, int max_input_len
 }
 // unified_attention: padded head sizes 64 and 128 (one configuration each)
 template <typename T, bool FP8>
-static void launch_unified(PrefillParams p, int head_size, int block_size, int max_q, int max_k,
+static int launch_unified(PrefillParams p, int head_size, int block_size, int max_q, int max_k,
                            int num_tokens, int num_heads, int batch, hipStream_t st) {
   const int gqa = p.num_heads / p.num_kv_heads;
   // decode-only launch: the flash-layout bandwidth kernel (unified_decode.hip)
@@ -750,16 +750,12 @@ static void launch_unified(PrefillParams p, int head_size, int block_size, int m
       const int by_len = (max_k + 4 * PF_BN - 1) / (4 * PF_BN);
       if (nseg > by_len) nseg = by_len;
       if (nseg > p.num_segments) nseg = p.num_segments;
+      if (nseg > 16) nseg = 16;
       if (nseg < 1) nseg = 1;
     }
     u.num_segments = nseg;
     if (unified_decode_supported(u)) {
-      if (unified_decode(u) != VLLM_AMD_OK) return;
-      if (nseg > 1) {
-        p.num_segments = nseg;
-        hipLaunchKernelGGL((unified_reduce_kernel<T>), dim3(num_tokens, num_heads), dim3(64), 0, st, p, 1, batch);
-      }
-      return;
+      return unified_decode(u);
     }
   }
   // GQA: rows = (token, q head of the group) pairs, grid.y = kv heads ("pf_rows" = 1: off)
@@ -784,11 +780,12 @@ static void launch_unified(PrefillParams p, int head_size, int block_size, int m
     if (p.num_segments > 1)
       hipLaunchKernelGGL((unified_reduce_kernel<T>), dim3(num_tokens, num_heads), dim3(64), 0, st, p, tpb,
                          batch);
-    return;
+    return VLLM_AMD_OK;
   }
   p.num_segments = 1;
   if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true>(p, block_size, max_q, num_heads, batch, st);
   else launch_cfg<T, FP8, 128, 1, 4, true>(p, block_size, max_q, num_heads, batch, st);
+  return VLLM_AMD_OK;
 }
 template <typename T, bool FP8, int D>
 static void launch_bs(const PrefillParams& p, int block_size, int max_input_len, int num_heads,
@@ -959,13 +956,15 @@ extern "C" int vllm_amd_unified_attention(
   p.num_segments = num_segments > 1 ? num_segments : 1;
   p.segm_stride = p.num_segments;
   hipStream_t st = (hipStream_t)stream;
+  int rc = VLLM_AMD_OK;
   if (dtype == VLLM_AMD_BF16) {
-    if (es == 2) launch_unified<bf16_t, false>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);
-    else launch_unified<bf16_t, true>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);
+    if (es == 2) rc = launch_unified<bf16_t, false>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);
+    else rc = launch_unified<bf16_t, true>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);
   } else {
-    if (es == 2) launch_unified<f16_t, false>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);
-    else launch_unified<f16_t, true>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);
+    if (es == 2) rc = launch_unified<f16_t, false>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);
+    else rc = launch_unified<f16_t, true>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);
   }
+  if (rc != VLLM_AMD_OK) return rc;
   VA_LAUNCH_CHECK(op);
   return VLLM_AMD_OK;
 }

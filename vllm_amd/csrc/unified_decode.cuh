@@ -26,7 +26,7 @@ struct UniDecodeParams {
 // true when every query of the launch may take the decode kernel (the caller has checked
 // max_seqlen_q == 1); false WITHOUT touching memory otherwise
 bool unified_decode_supported(const UniDecodeParams& p);
-// main kernel only; with num_segments > 1 the caller merges the partials
+// main kernel and, with num_segments > 1 (at most 16), the merge of the segment partials
 int unified_decode(const UniDecodeParams& p);
 
 }  // namespace va

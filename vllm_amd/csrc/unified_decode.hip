@@ -32,6 +32,8 @@
 
 namespace va {
 
+extern int g_uni_decode;
+
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -52,7 +54,7 @@ __device__ __forceinline__ typename DwVec<N>::type nt_load(const uint8_t* p) {
 }
 
 template <typename T, bool FP8, int D, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodeParams p, int sub_shift) {
+__global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodeParams p, int sub_shift, int xcd_group) {
   constexpr int ES = FP8 ? 1 : 2;             // cache element bytes
   constexpr int TILES = FP8 ? 4 : 2;          // 16-token tiles per step
   constexpr int STEP_TOK = TILES * 16;
@@ -66,7 +68,16 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c16 = lane & 15, g4 = lane >> 4;
-  const int kvh = blockIdx.x % p.num_kv_heads, seq = blockIdx.x / p.num_kv_heads;
+  // Launches of more than one round of workgroups: consecutive hardware ids go to different XCDs
+  // (id % 8); remapped so that the kv heads of a sequence -- adjacent 128-byte pieces of the same
+  // token rows -- are fetched through ONE XCD's L2 at about the same time (256 x 4096 fp8:
+  // 5.6 -> 5.8 TB/s, 512 x 2048: 5.55 -> 5.94; no gain below two rounds of workgroups).
+  int wg = blockIdx.x;
+  if (xcd_group) {
+    const int nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
+    wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  const int kvh = wg % p.num_kv_heads, seq = wg / p.num_kv_heads;
   const int seg = blockIdx.y;
   const int G = p.num_heads / p.num_kv_heads;   // <= 16
   const int head0 = kvh * G;
@@ -383,14 +394,76 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   }
 }
 
+// Merge of the key segments of a split launch (reduce_segments,
+// triton_unified_attention.py:499-586): one wave per (sequence, q head).  Lane s holds the max /
+// sum of segment s (at most 16 segments), the weights come from two 16-lane butterflies, and
+// the 16 partial rows are loaded back to back (segments past the sequence's last one re-read
+// that last one with weight 0), so the kernel is two dependent memory round trips.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void ua_decode_reduce_kernel(const UniDecodeParams p) {
+  constexpr int VPL = D / 64;   // outputs per lane
+  const int lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= p.num_seqs * p.num_heads) return;
+  const int seq = pair / p.num_heads, head = pair % p.num_heads;
+  const int qtok = p.cu_seqlens_q[seq];
+  if (p.cu_seqlens_q[seq + 1] - qtok != 1) return;
+  const int ntiles = (p.seq_lens[seq] + 63) >> 6;
+  const int tps = (ntiles + p.num_segments - 1) / p.num_segments;
+  const int nseg = tps > 0 ? (ntiles + tps - 1) / tps : 0;   // segments the main kernel wrote
+  const int64_t row = ((int64_t)qtok * p.num_heads + head) * p.segm_stride;
+  float acc[VPL], l = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) acc[j] = 0.f;
+  if (nseg > 0) {
+    const float ms = lane < nseg ? p.segm_max[row + lane] : -INFINITY;
+    const float ls = lane < nseg ? p.segm_sum[row + lane] : 0.f;
+    typedef __attribute__((ext_vector_type(VPL))) float fv;
+    fv part[16];
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+      part[s2] = *reinterpret_cast<const fv*>(p.segm_out + (row + min(s2, nseg - 1)) * D + VPL * lane);
+    float mx = ms;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    const float w = ms == -INFINITY ? 0.f : fast_exp2(ms - mx);
+    l = ls * w;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) l += __shfl_xor(l, m, 64);
+    l = __shfl(l, 0, 64);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const float ws = __shfl(w, s2, 64);
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) acc[j] += part[s2][j] * ws;
+    }
+  }
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  const int64_t oidx = (int64_t)qtok * p.o_stride_t + (int64_t)head * p.o_stride_h + VPL * lane;
+  if (p.out_scale) {
+    const float oi = inv * (1.0f / *p.out_scale);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) ((uint8_t*)p.out)[oidx + j] = f32_to_fp8(acc[j] * oi);
+  } else {
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) ((T*)p.out)[oidx + j] = from_f32<T>(acc[j] * inv);
+  }
+}
+
 template <typename T, bool FP8, int D>
 int launch(const UniDecodeParams& p) {
   constexpr int NW = 4;
   int sub_shift = 0;
   while ((16 << sub_shift) < p.block_size) ++sub_shift;
   const dim3 grid((unsigned)(p.num_seqs * p.num_kv_heads), (unsigned)(p.num_segments > 1 ? p.num_segments : 1));
-  hipLaunchKernelGGL((ua_decode_kernel<T, FP8, D, NW>), grid, dim3(NW * 64), 0, p.stream, p, sub_shift);
+  hipLaunchKernelGGL((ua_decode_kernel<T, FP8, D, NW>), grid, dim3(NW * 64), 0, p.stream, p, sub_shift,
+                     g_uni_decode == 2 ? 1 : g_uni_decode == 3 ? 0 : (grid.x * grid.y >= 1024 ? 1 : 0));
   VA_LAUNCH_CHECK("unified_attention decode launch");
+  if (p.num_segments > 1) {
+    hipLaunchKernelGGL((ua_decode_reduce_kernel<T, D>), dim3((unsigned)((p.num_seqs * p.num_heads + 3) / 4)),
+                       dim3(256), 0, p.stream, p);
+    VA_LAUNCH_CHECK("unified_attention decode merge launch");
+  }
   return VLLM_AMD_OK;
 }
 
@@ -407,7 +480,7 @@ bool unified_decode_supported(const UniDecodeParams& p) {
   if (p.q_stride_t % 8 || p.q_stride_h % 8 || (((uintptr_t)p.q) & 15)) return false;
   // one thread stores 8 consecutive outputs: 16 bytes (8 with an fp8 output)
   if (p.o_stride_t % 8 || p.o_stride_h % 8 || (((uintptr_t)p.out) & (p.out_scale ? 7 : 15))) return false;
-  if (p.num_segments > 1 && (((uintptr_t)p.segm_out) & 15)) return false;
+  if (p.num_segments > 16 || (p.num_segments > 1 && (((uintptr_t)p.segm_out) & 15))) return false;
   return true;
 }
 
