@@ -124,11 +124,12 @@ def test_unified_mixed_batch_packed(oracle, heads, D, mode):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("block_size", [16, 32])
 @pytest.mark.parametrize("fp8", [False, True])
-@pytest.mark.parametrize("nseq", [3, 140])
+@pytest.mark.parametrize("nseq", [3, 140, 260])
 def test_unified_decode_kernel(oracle, dtype, block_size, fp8, nseq):
-    """The flash-layout decode kernel (unified_decode.hip): split over key segments (few
-    sequences) and unsplit (>= 512 workgroups), both block sizes and dtypes, lengths around the
-    step (32 / 64 tokens), the page and the 64-token segment tile."""
+    """The flash-layout decode kernel (unified_decode.hip): split over key segments (3 and 140
+    sequences: 12 and 560 workgroups) and unsplit with the XCD-grouped order (260: 1040), both
+    block sizes and dtypes, lengths around the step (32 / 64 tokens), the page and the
+    64-token segment tile."""
     lens = [1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 257, 700, 1, 16, 17]
     seqs = [(1, lens[i % len(lens)] + (i // len(lens))) for i in range(nseq)]
     if nseq == 3:
@@ -141,9 +142,10 @@ def test_unified_decode_kernel(oracle, dtype, block_size, fp8, nseq):
 @pytest.mark.parametrize("fp8", [False, True])
 def test_unified_decode_kernel_features(oracle, mode, fp8):
     """Window edges inside / across steps and segments, ALiBi, softcap, fp8 output and a
-    head-major (HND) cache allocation, unsplit launch (520 workgroups)."""
+    head-major (HND) cache allocation; unsplit launch (1040 workgroups; the split launches of
+    these features are in test_unified_decode_batches)."""
     lens = [5, 100, 129, 300, 640, 1000]
-    seqs = [(1, lens[i % len(lens)] + i // 6) for i in range(130)]
+    seqs = [(1, lens[i % len(lens)] + i // 6) for i in range(260)]
     c = make_unified_case(seqs, 8, 4, 64 if mode == "alibi" else 128, 16, torch.bfloat16, fp8=fp8, seed=77,
                           kv_scale=0.5)
     slopes = 2.0 ** -(torch.arange(8).float() * 0.25 + 1) if mode == "alibi" else None

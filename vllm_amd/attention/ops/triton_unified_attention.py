@@ -41,12 +41,12 @@ def unified_attention(q, k, v, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_s
         assert out.dtype in _FP8
     else:
         assert out.dtype == q.dtype
-    # few decode sequences: scratch for the split over the keys, allocated here as the
-    # reference does for its 3-D kernel (:659-683, NUM_SEGMENTS = 16)
+    # decode batches of less than two rounds of workgroups: scratch for the split over the
+    # keys, allocated here as the reference does for its 3-D kernel (:659-683, NUM_SEGMENTS = 16)
     segm_out = segm_max = segm_sum = None
     nseg = 0
     num_kv_heads = k.shape[2]
-    if max_seqlen_q == 1 and num_seqs * num_kv_heads < 512 and q.shape[1] > num_kv_heads:
+    if max_seqlen_q == 1 and num_seqs * num_kv_heads < 1024:
         nseg = 16
         segm_out = torch.empty((q.shape[0], q.shape[1], nseg, q.shape[2]), dtype=torch.float32,
                                device=q.device)
