@@ -155,6 +155,22 @@ def test_unified_decode_kernel_features(oracle, mode, fp8):
         out_scale=torch.tensor([0.02]) if mode == "fp8_out" else None, view=view)
 
 
+@pytest.mark.parametrize("heads", [(8, 2), (32, 8), (4, 4)])
+@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("mode", ["plain", "window", "alibi", "softcap"])
+def test_unified_mixed_batch_two_kernels(oracle, heads, D, fp8, mode):
+    """Mixed batches of >= 16 sequences: the decode kernel takes the sequences of query length
+    1 (also a one-token prefill chunk), the tile kernel the rest."""
+    seqs = [(1, 500), (70, 70), (1, 64), (33, 200), (1, 1), (9, 9), (1, 129), (150, 1100), (1, 31),
+            (1, 1000), (2, 2), (1, 333), (1, 65), (17, 80), (1, 256), (1, 255), (1, 77), (5, 600)]
+    c = make_unified_case(seqs, heads[0], heads[1], D, 16, torch.bfloat16, fp8=fp8, seed=heads[0] + D,
+                          kv_scale=0.5)
+    slopes = 2.0 ** -(torch.arange(heads[0]).float() * 0.25 + 1) if mode == "alibi" else None
+    run(oracle, c, torch.bfloat16, fp8=fp8, alibi=slopes, window=40 if mode == "window" else None,
+        softcap=20.0 if mode == "softcap" else 0.0)
+
+
 def test_unified_decode_kernel_equals_packed(oracle):
     """Same decode batch through the decode kernel and the packed tile kernel ("uni_decode" = 0)."""
     from vllm_amd import _lib

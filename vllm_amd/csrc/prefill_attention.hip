@@ -45,6 +45,7 @@ struct PrefillParams {
   // split over the keys (PACK launches with one row block): segment partials, caller-allocated
   float* segm_out; float* segm_max; float* segm_sum;
   int num_segments;     // segments of this launch (1 = no split)
+  int flat_batch;       // UNI: > 0 = number of sequences, grid.x enumerates the row blocks of all of them
   int segm_stride;      // segments the buffers were allocated for
 };
 
@@ -114,11 +115,27 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   // split launches (PACK, one row block per sequence): blockIdx.x is the key segment
   const bool split = PACK && p.num_segments > 1;
   const int seg = split ? wg % gridDim.x : 0;
-  const int start_m = split ? 0 : gridDim.x - 1 - wg % gridDim.x;
   const int gqa = p.num_heads / p.num_kv_heads;
-  const int head = (wg / gridDim.x) % gridDim.y, seq = wg / (gridDim.x * gridDim.y);
-  const int kvh = PACK ? head : head / gqa;
   const int tpb = PACK ? PF_BM / gqa : PF_BM;   // query tokens per workgroup
+  const int head = (wg / gridDim.x) % gridDim.y;
+  int start_m = split ? 0 : gridDim.x - 1 - wg % gridDim.x;
+  int seq = wg / (gridDim.x * gridDim.y);
+  if (UNI && p.flat_batch > 0) {
+    // grid.x enumerates the row blocks of ALL sequences (cdiv(num_tokens, tpb) + num_seqs is an
+    // upper bound, as in the reference, :612-626), so a mixed batch -- one long prefill chunk
+    // among decode tokens -- launches no empty workgroups for the short sequences; the
+    // sequence is the last one whose first block cu[i] / tpb + i is <= the block id
+    // (find_seq_idx, :33-48)
+    const int g = start_m;
+    int lo = 0, hi = p.flat_batch;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (p.b_start_loc[mid] / tpb + mid <= g) lo = mid; else hi = mid;
+    }
+    seq = lo;
+    start_m = g - (p.b_start_loc[seq] / tpb + seq);
+  }
+  const int kvh = PACK ? head : head / gqa;
   // global row id m = start_m PF_BM + local row -> (query token within the sequence's new
   // tokens, q head); PACK: local row = token-major (token, head in group)
   auto row_tok = [&](int m) { return PACK ? start_m * tpb + (m - start_m * PF_BM) / gqa : m; };
@@ -725,8 +742,14 @@ template <typename T, bool FP8>
 static int launch_unified(PrefillParams p, int head_size, int block_size, int max_q, int max_k,
                            int num_tokens, int num_heads, int batch, hipStream_t st) {
   const int gqa = p.num_heads / p.num_kv_heads;
-  // decode-only launch: the flash-layout bandwidth kernel (unified_decode.hip)
-  if (max_q == 1 && g_uni_decode && g_pf_rows != 1) {
+  // The flash-layout bandwidth kernel (unified_decode.hip) takes decode-only launches, and the
+  // decode tokens of a mixed batch of >= 16 sequences (the V1 engine's usual step: a few prefill
+  // chunks among many decodes; as the reference's ROCm backend pairs its prefill kernel with
+  // the paged-attention op, chunked_prefill_paged_decode.py:318-338): it skips every sequence
+  // whose query length is not 1, the tile kernel below then skips those whose length is.
+  // num_tokens == batch * max_q means every query has max_q > 1 tokens: nothing to split off.
+  const bool mixed = max_q > 1 && batch >= 16 && (int64_t)num_tokens < (int64_t)batch * max_q;
+  if ((max_q == 1 || mixed) && g_uni_decode && g_pf_rows != 1) {
     UniDecodeParams u;
     u.out = p.o; u.q = p.q; u.k_cache = p.k_cache; u.v_cache = p.v_cache;
     u.cu_seqlens_q = p.b_start_loc; u.seq_lens = p.b_seq_len; u.block_table = p.b_loc;
@@ -749,7 +772,7 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
     // smallest segment count within 5 % of the best estimate (513..1023 workgroups: ~1.3
     // rounds instead of 2); few sequences: as many segments of >= 256 tokens as allowed.
     int nseg = 1;
-    if (p.num_segments > 1) {
+    if (p.num_segments > 1 && !mixed) {
       const int wgs = batch * p.num_kv_heads;
       int cap = (max_k + 4 * PF_BN - 1) / (4 * PF_BN);
       if (cap > p.num_segments) cap = p.num_segments;
@@ -765,7 +788,9 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
     }
     u.num_segments = nseg;
     if (unified_decode_supported(u)) {
-      return unified_decode(u);
+      const int rc = unified_decode(u);
+      if (!mixed || rc != VLLM_AMD_OK) return rc;
+      p.skip_decode = 1;
     }
   }
   // GQA: rows = (token, q head of the group) pairs, grid.y = kv heads ("pf_rows" = 1: off)
@@ -784,6 +809,11 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
       rows = p.num_segments * bm;
     } else {
       p.num_segments = 1;
+      if (num_tokens > 0) {   // one grid entry per row block of any sequence
+        p.flat_batch = batch;
+        rows = (num_tokens / tpb + batch) * bm;
+        batch = 1;
+      }
     }
     if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true, true>(p, block_size, rows, p.num_kv_heads, batch, st);
     else launch_cfg<T, FP8, 128, 1, 4, true, true>(p, block_size, rows, p.num_kv_heads, batch, st);
@@ -793,6 +823,12 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
     return VLLM_AMD_OK;
   }
   p.num_segments = 1;
+  if (num_tokens > 0) {
+    const int bm = head_size <= 64 ? 128 : 64;
+    p.flat_batch = batch;
+    max_q = (num_tokens / bm + batch) * bm;
+    batch = 1;
+  }
   if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true>(p, block_size, max_q, num_heads, batch, st);
   else launch_cfg<T, FP8, 128, 1, 4, true>(p, block_size, max_q, num_heads, batch, st);
   return VLLM_AMD_OK;
@@ -884,6 +920,7 @@ extern "C" int vllm_amd_context_attention_fwd(
   p.softcap = 0.f;
   p.segm_out = p.segm_max = p.segm_sum = nullptr;
   p.num_segments = p.segm_stride = 1;
+  p.flat_batch = 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VLLM_AMD_BF16) {
     if (es == 2) launch_d<bf16_t, false>(p, head_size, block_size, max_input_len, num_heads, batch, st);
@@ -965,6 +1002,7 @@ extern "C" int vllm_amd_unified_attention(
   p.segm_out = segm_output; p.segm_max = segm_max; p.segm_sum = segm_expsum;
   p.num_segments = num_segments > 1 ? num_segments : 1;
   p.segm_stride = p.num_segments;
+  p.flat_batch = 0;
   hipStream_t st = (hipStream_t)stream;
   int rc = VLLM_AMD_OK;
   if (dtype == VLLM_AMD_BF16) {
