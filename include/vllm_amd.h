@@ -287,7 +287,7 @@ int vllm_amd_context_attention_fwd(
     int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, int64_t o_stride_t,
     int64_t o_stride_h, int64_t kc_block_stride, int64_t kc_head_stride,
     int64_t vc_block_stride, int64_t vc_head_stride, float sm_scale, int sliding_window,
-    int skip_decode, int dtype, int kv_cache_dtype, void* stream);
+    int skip_decode, int num_tokens, int dtype, int kv_cache_dtype, void* stream);
 
 /* Replaces unified_attention (vllm/attention/ops/triton_unified_attention.py:588-700; Triton
  * kernels kernel_unified_attention_2d :52-272 / _3d :276-586): the V1 engine's attention over
@@ -310,13 +310,17 @@ int vllm_amd_context_attention_fwd(
  * Supported here: f16 / bf16 queries (no fp8 queries: q_descale is "not supported" in the
  * reference either, :609), head_size a multiple of 8 (16 with an fp8 cache) up to 128,
  * block_size 16 / 32.  With GQA the tile rows are (token, q head of the group) pairs, so a
- * decode token streams its K / V once per group.
+ * decode token streams its K / V once per group.  Sequences of query length 1 take a dedicated
+ * bandwidth kernel (head_size 64 / 128, group <= 16; unified_decode.hip) when the whole launch
+ * is decode-only (max_seqlen_q == 1) or has >= 16 sequences; the grid of the tile kernel has
+ * one entry per row block of any sequence when num_tokens is given (> 0).
+ *   num_tokens = rows of q (total query tokens of the launch); max_seqlen_k >= every seqused_k
  *   segm_output float [num_tokens, num_heads, num_segments, head_size], segm_max / segm_expsum
  *            float [num_tokens, num_heads, num_segments]: caller-allocated scratch as in the
  *            reference's 3-D path (:659-683; NUM_SEGMENTS = 16 there), or NULL / num_segments
  *            <= 1.  When given and every sequence fits one row block (decode), the keys of a
- *            sequence are split over up to num_segments workgroups and merged by a second
- *            kernel (reduce_segments, :499-586); contents afterwards are unspecified. */
+ *            sequence are split over up to min(num_segments, 16) workgroups and merged by a
+ *            second kernel (reduce_segments, :499-586); contents afterwards are unspecified. */
 int vllm_amd_unified_attention(
     void* out, const void* q, const void* k_cache, const void* v_cache,
     const int* cu_seqlens_q, const int* seqused_k, const int* block_table,
@@ -344,6 +348,8 @@ int vllm_amd_unified_attention(
 /*                 12, 13 = 32x128 tile (1 / 2 K blocks per barrier)            */
 /*   "pf_rows":    query rows per workgroup of the prefill kernels (0 = default,    */
 /*                 64 / 128); 1 = unified_attention without GQA packing          */
+/*   "uni_decode": 0 = unified_attention never uses its decode kernel (1 =     */
+/*                 default; 2 / 3 = XCD-grouped workgroup order always / never) */
 /*   "cache_runs": 0 = reshape_and_cache always per token (no run detection)    */
 /*   "mm_splitk":  K slices per output tile of the direct-to-LDS kernels        */
 /*                 (0 = heuristic, 1 = never split, n = n slices; reduced       */

@@ -45,7 +45,8 @@ struct PrefillParams {
   // split over the keys (PACK launches with one row block): segment partials, caller-allocated
   float* segm_out; float* segm_max; float* segm_sum;
   int num_segments;     // segments of this launch (1 = no split)
-  int flat_batch;       // UNI: > 0 = number of sequences, grid.x enumerates the row blocks of all of them
+  int flat_batch;       // > 0 = number of sequences: grid.x enumerates the row blocks of all of them,
+  int flat_tokens;      //   at most flat_tokens / tokens_per_block + flat_batch (flat_tokens = rows of q)
   int segm_stride;      // segments the buffers were allocated for
 };
 
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   const int head = (wg / gridDim.x) % gridDim.y;
   int start_m = split ? 0 : gridDim.x - 1 - wg % gridDim.x;
   int seq = wg / (gridDim.x * gridDim.y);
-  if (UNI && p.flat_batch > 0) {
+  if (!split && p.flat_batch > 0) {
     // grid.x enumerates the row blocks of ALL sequences (cdiv(num_tokens, tpb) + num_seqs is an
     // upper bound, as in the reference, :612-626), so a mixed batch -- one long prefill chunk
     // among decode tokens -- launches no empty workgroups for the short sequences; the
@@ -731,7 +732,11 @@ template <typename T, bool FP8, int D, int MT, int NW, bool UNI = false, bool PA
 static void launch_cfg(const PrefillParams& p, int block_size, int max_input_len, int num_heads,
                        int batch, hipStream_t st) {
   constexpr int BM = 16 * MT * NW;
-  const dim3 grid((max_input_len + BM - 1) / BM, num_heads, batch);
+  dim3 grid((max_input_len + BM - 1) / BM, num_heads, batch);
+  if (p.flat_batch > 0 && p.num_segments <= 1) {
+    const int tpb = PACK ? BM / (p.num_heads / p.num_kv_heads) : BM;
+    grid = dim3(p.flat_tokens / tpb + p.flat_batch, num_heads, 1);
+  }
   if (block_size == 16)
     hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 16, MT, NW, UNI, PACK>), grid, dim3(64 * NW), 0, st, p);
   else
@@ -809,11 +814,6 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
       rows = p.num_segments * bm;
     } else {
       p.num_segments = 1;
-      if (num_tokens > 0) {   // one grid entry per row block of any sequence
-        p.flat_batch = batch;
-        rows = (num_tokens / tpb + batch) * bm;
-        batch = 1;
-      }
     }
     if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true, true>(p, block_size, rows, p.num_kv_heads, batch, st);
     else launch_cfg<T, FP8, 128, 1, 4, true, true>(p, block_size, rows, p.num_kv_heads, batch, st);
@@ -823,12 +823,6 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
     return VLLM_AMD_OK;
   }
   p.num_segments = 1;
-  if (num_tokens > 0) {
-    const int bm = head_size <= 64 ? 128 : 64;
-    p.flat_batch = batch;
-    max_q = (num_tokens / bm + batch) * bm;
-    batch = 1;
-  }
   if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true>(p, block_size, max_q, num_heads, batch, st);
   else launch_cfg<T, FP8, 128, 1, 4, true>(p, block_size, max_q, num_heads, batch, st);
   return VLLM_AMD_OK;
@@ -868,8 +862,8 @@ extern "C" int vllm_amd_context_attention_fwd(
     int64_t b_loc_stride, int64_t q_stride_t, int64_t q_stride_h, int64_t k_stride_t,
     int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, int64_t o_stride_t,
     int64_t o_stride_h, int64_t kc_block_stride, int64_t kc_head_stride, int64_t vc_block_stride,
-    int64_t vc_head_stride, float sm_scale, int sliding_window, int skip_decode, int dtype,
-    int kv_cache_dtype, void* stream) {
+    int64_t vc_head_stride, float sm_scale, int sliding_window, int skip_decode, int num_tokens,
+    int dtype, int kv_cache_dtype, void* stream) {
   const char* op = "context_attention_fwd";
   VA_REQUIRE(batch >= 0 && max_input_len >= 0, VLLM_AMD_EINVAL, "%s: negative size", op);
   if (batch == 0 || max_input_len == 0 || num_heads == 0) return VLLM_AMD_OK;
@@ -920,7 +914,8 @@ extern "C" int vllm_amd_context_attention_fwd(
   p.softcap = 0.f;
   p.segm_out = p.segm_max = p.segm_sum = nullptr;
   p.num_segments = p.segm_stride = 1;
-  p.flat_batch = 0;
+  p.flat_batch = num_tokens > 0 ? batch : 0;
+  p.flat_tokens = num_tokens;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VLLM_AMD_BF16) {
     if (es == 2) launch_d<bf16_t, false>(p, head_size, block_size, max_input_len, num_heads, batch, st);
@@ -1002,7 +997,10 @@ extern "C" int vllm_amd_unified_attention(
   p.segm_out = segm_output; p.segm_max = segm_max; p.segm_sum = segm_expsum;
   p.num_segments = num_segments > 1 ? num_segments : 1;
   p.segm_stride = p.num_segments;
-  p.flat_batch = 0;
+  // one grid entry per row block of any sequence (launch_cfg) when the caller says how many
+  // query tokens there are
+  p.flat_batch = num_tokens > 0 ? num_seqs : 0;
+  p.flat_tokens = num_tokens;
   hipStream_t st = (hipStream_t)stream;
   int rc = VLLM_AMD_OK;
   if (dtype == VLLM_AMD_BF16) {
