@@ -274,6 +274,10 @@ int vllm_amd_swap_blocks(const void* src, void* dst, int64_t block_bytes,
  *                     as in the reference's alibi kernel)
  *   fp8_out_scale     float[1] or NULL: o is e4m3 bytes = clamp(acc / l / scale)
  *   sliding_window    <= 0 disables; skip_decode: sequences with one query token are skipped
+ *   num_tokens        rows of q (total new tokens), or <= 0 if unknown: when given, the grid has
+ *                     one entry per row block of any sequence instead of max_input_len-many
+ *                     blocks for every sequence (mixed batches: few long chunks among many
+ *                     one-token sequences launch no empty workgroups)
  * Supported here: f16 / bf16 queries, head_size a multiple of 8 (16 with an fp8 cache) up to
  * 128 (padded to a multiple of 32 inside the kernel), block_size 16/32,
  * kv_cache_dtype auto / fp8_e4m3. */

@@ -52,7 +52,7 @@ SIGNATURES = {
     "vllm_amd_context_attention_fwd": [
         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
         _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _i,
-        _i, _i, _vp],
+        _i, _i, _i, _vp],
     "vllm_amd_unified_attention": [
         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
         _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _f, _i, _i, _vp,

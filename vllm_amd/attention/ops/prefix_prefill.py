@@ -69,4 +69,4 @@ def context_attention_fwd(q, k, v, o, kv_cache_dtype: str, k_cache, v_cache, b_l
             int(max_input_len), b_loc.stride(0), q.stride(0), q.stride(1), k.stride(0),
             k.stride(1), v.stride(0), v.stride(1), o.stride(0), o.stride(1), k_cache.stride(0),
             k_cache.stride(1), v_cache.stride(0), v_cache.stride(1), float(sm_scale),
-            int(sliding_window), int(bool(skip_decode)), _DT[q.dtype], kvd, _stream(q)))
+            int(sliding_window), int(bool(skip_decode)), q.shape[0], _DT[q.dtype], kvd, _stream(q)))
