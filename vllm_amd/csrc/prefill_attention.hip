@@ -93,7 +93,9 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   constexpr int K8_ITEMS = (PF_BN * (D / 16) + PF_THREADS - 1) / PF_THREADS;   // fp8 K
   constexpr int V16_ITEMS = (V16_TOTAL + PF_THREADS - 1) / PF_THREADS;   // 16-bit V: (d, 8 tok)
   constexpr int V8_ITEMS = (D * 4 + PF_THREADS - 1) / PF_THREADS;   // fp8 V: (d, 16 tok)
-  constexpr int NSTG = K16_ITEMS;            // staging registers per operand (>= every count)
+  // staging registers per operand (>= every count; unified_attention over an fp8 cache never
+  // stages 16-bit items)
+  constexpr int NSTG = (UNI && FP8) ? K8_ITEMS : K16_ITEMS;
   static_assert(K16_ITEMS >= K8_ITEMS && K16_ITEMS >= V16_ITEMS && K16_ITEMS >= V8_ITEMS, "");
   __shared__ __attribute__((aligned(16))) uint8_t lds[K_BYTES + V_BYTES];
   uint8_t* lds_k = lds;
