@@ -1,0 +1,126 @@
+"""GPU parity of the V1 attention backend mirror (vllm_amd/v1/attention/backends/triton_attn.py,
+reference vllm/v1/attention/backends/triton_attn.py:200-384): TritonAttentionImpl.forward =
+cache write + attention on a mixed batch, against the oracle's reshape_and_cache_flash +
+unified_attention, through both of the reference's paths (unified_attention over the flash
+layout; VLLM_V1_USE_PREFILL_DECODE_ATTENTION: context_attention_fwd + paged_attention_rocm over
+the x layout)."""
+import types
+
+import pytest
+import torch
+
+from helpers import make_unified_case
+
+pytestmark = pytest.mark.gpu
+
+SEQS = [(1, 500), (70, 70), (1, 64), (33, 200), (1, 1), (9, 9), (1, 129), (150, 1100), (1, 31),
+        (1, 1000), (2, 2), (1, 333), (1, 65), (17, 80), (1, 256), (1, 255), (1, 77), (5, 600)]
+
+
+def _to_x_layout(kc_f, vc_f):
+    """flash [NB, BS, KVH, D] -> x layout K [NB, KVH, D/x, BS, x], V [NB, KVH, D, BS]"""
+    NB, BS, KVH, D = kc_f.shape
+    x = 16 // kc_f.element_size()
+    kx = kc_f.permute(0, 2, 3, 1).reshape(NB, KVH, D // x, x, BS).permute(0, 1, 2, 4, 3).contiguous()
+    vx = vc_f.permute(0, 2, 3, 1).contiguous()
+    return kx, vx
+
+
+@pytest.mark.parametrize("path", ["unified", "prefill_decode"])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("heads", [(8, 2), (32, 8)])
+@pytest.mark.parametrize("mode", ["plain", "alibi", "window", "softcap"])
+def test_triton_attention_impl_forward(oracle, monkeypatch, path, fp8, heads, mode):
+    if path == "prefill_decode" and mode in ("window", "softcap"):
+        pytest.skip("the prefill + paged-decode path has no decode-side window / soft cap")
+    from vllm_amd.v1.attention.backends import (TritonAttentionBackend, TritonAttentionImpl,
+                                                TritonAttentionMetadataBuilder)
+    monkeypatch.setenv("VLLM_V1_USE_PREFILL_DECODE_ATTENTION", "1" if path == "prefill_decode" else "0")
+    H, KVH, D, BS, dtype = heads[0], heads[1], 128, 16, torch.bfloat16
+    c = make_unified_case(SEQS, H, KVH, D, BS, dtype, fp8=fp8, seed=H + fp8, kv_scale=0.5)
+    T = c["q"].shape[0]
+    g = torch.Generator().manual_seed(7)
+    key = torch.randn((T + 3, KVH, D), generator=g).to(dtype)     # 3 padding tokens at the end
+    value = torch.randn((T + 3, KVH, D), generator=g).to(dtype)
+    query = torch.cat([c["q"], torch.zeros((3, H, D), dtype=dtype)])
+    slots = []
+    for b, (ql, kl) in enumerate(SEQS):
+        for pos in range(kl - ql, kl):
+            slots.append(int(c["block_table"][b, pos // BS]) * BS + pos % BS)
+    slots = torch.tensor(slots + [-1, -1, -1], dtype=torch.int64)
+    kvd = "fp8" if fp8 else "auto"
+    sc = float(c["scale"]) if fp8 else 1.0
+    window = 40 if mode == "window" else None
+    softcap = 20.0 if mode == "softcap" else None
+    slopes = [2.0 ** -(0.25 * i + 1) for i in range(H)] if mode == "alibi" else None
+
+    # expected: the oracle writes the new tokens, then attends
+    kc_o, vc_o = c["k"].clone(), c["v"].clone()
+    oracle.reshape_and_cache_flash(key[:T], value[:T], kc_o, vc_o, slots[:T], kvd, sc, sc)
+    ref = torch.zeros((T, H, D), dtype=dtype)
+    ws = (window - 1, 0) if window is not None else (-1, -1)
+    kd = c["scale"] if fp8 else None
+    oracle.unified_attention(c["q"], kc_o, vc_o, ref, c["cu_seqlens_q"], c["max_seqlen_q"],
+                             c["seqused_k"], c["max_seqlen_k"], D ** -0.5, True, ws, c["block_table"],
+                             softcap or 0.0, None, kd, kd,
+                             None if slopes is None else torch.tensor(slopes), None)
+
+    if path == "prefill_decode":
+        # this path reads the NEW tokens of a prefill chunk from the dense key / value, not from
+        # the (quantised) cache: expected rows of the chunks = the oracle's context_attention_fwd
+        kx_o, vx_o = _to_x_layout(kc_o, vc_o)
+        ref_pf = torch.zeros_like(ref)
+        oracle.context_attention_fwd(c["q"], key[:T], value[:T], ref_pf, kvd, kx_o, vx_o, c["block_table"],
+                                     c["cu_seqlens_q"], c["seqused_k"], c["max_seqlen_k"], c["max_seqlen_q"],
+                                     sc, sc, None if slopes is None else torch.tensor(slopes), None,
+                                     D ** -0.5)
+        for b, (ql, _) in enumerate(SEQS):
+            if ql > 1:
+                lo = int(c["cu_seqlens_q"][b])
+                ref[lo:lo + ql] = ref_pf[lo:lo + ql]
+
+    # the backend
+    dev = torch.device("cuda", 0)
+    impl = TritonAttentionImpl(H, D, D ** -0.5, KVH, slopes, window, kvd, softcap)
+    if path == "unified":
+        kv_cache = torch.stack([c["k"], c["v"]]).to(dev)
+        assert kv_cache.shape == TritonAttentionBackend.get_kv_cache_shape(c["k"].shape[0], BS, KVH, D)
+    else:
+        kx, vx = _to_x_layout(c["k"], c["v"])
+        kv_cache = torch.stack([kx.reshape(kx.shape[0], -1), vx.reshape(vx.shape[0], -1)]).to(dev)
+    layer = types.SimpleNamespace(_k_scale=torch.tensor(sc, device=dev), _v_scale=torch.tensor(sc, device=dev),
+                                  _q_scale=1.0)
+    common = types.SimpleNamespace(
+        num_actual_tokens=T, max_query_len=c["max_seqlen_q"], query_start_loc=c["cu_seqlens_q"].to(dev),
+        seq_lens=c["seqused_k"].to(dev), seq_lens_cpu=c["seqused_k"], block_table_tensor=c["block_table"].to(dev),
+        slot_mapping=slots.to(dev))
+    builder = TritonAttentionMetadataBuilder(types.SimpleNamespace(block_size=BS), None, dev)
+    md = builder.build(0, common)
+    assert md.max_seq_len == c["max_seqlen_k"] and md.use_cascade is False
+    output = torch.full((T + 3, H, D), 7.0, dtype=dtype, device=dev)
+    ret = impl.forward(layer, query.to(dev), key.to(dev), value.to(dev), kv_cache, md, output=output)
+    assert ret is output
+    torch.cuda.synchronize()
+
+    # cache contents: bit-exact with the oracle's write (compared as integers: unused slots of
+    # a 16-bit cache hold NaN on purpose)
+    bits = lambda t: t.contiguous().view(torch.int16 if t.element_size() == 2 else torch.uint8)
+    if path == "unified":
+        assert torch.equal(bits(kv_cache[0].cpu()), bits(kc_o)) and torch.equal(bits(kv_cache[1].cpu()), bits(vc_o))
+    else:
+        kx_o, vx_o = _to_x_layout(kc_o, vc_o)
+        assert torch.equal(bits(kv_cache[0].cpu().view(kx_o.shape)), bits(kx_o))
+        assert torch.equal(bits(kv_cache[1].cpu().view(vx_o.shape)), bits(vx_o))
+    torch.testing.assert_close(output[:T].cpu().float(), ref.float(), atol=1.5e-2, rtol=1e-2)
+    assert torch.all(output[T:] == 7.0), "padding rows past num_actual_tokens must stay untouched"
+
+
+def test_profiling_run_and_unsupported():
+    from vllm_amd.v1.attention.backends import TritonAttentionImpl
+    impl = TritonAttentionImpl(8, 128, 0.1, 2, None, None, "auto")
+    out = torch.zeros((2, 8, 128), dtype=torch.bfloat16, device="cuda")
+    assert impl.forward(None, out, None, None, None, None, output=out) is out   # attn_metadata None
+    with pytest.raises(ValueError, match="Head size 80 is not supported by TritonAttention"):
+        TritonAttentionImpl(8, 80, 0.1, 2, None, None, "auto")
+    with pytest.raises(NotImplementedError, match="Encoder self-attention"):
+        TritonAttentionImpl(8, 128, 0.1, 2, None, None, "auto", attn_type="encoder")

@@ -127,3 +127,50 @@ def test_tp2_gloo_sharded_attention_and_row_parallel():
     assert ok_attn, "KV-head-sharded attention must equal the unsharded result exactly"
     assert err < 0.06, err            # two fp8 quantisations (~2^-4 relative each, averaged over K)
     assert out_of_place
+
+
+def test_v1_backend_host_logic():
+    """TritonAttentionBackend / MetadataBuilder / Impl constructor: the reference's contract
+    (vllm/v1/attention/backends/triton_attn.py:58-265) without a GPU."""
+    import types
+    from vllm_amd.v1.attention.backends import (TritonAttentionBackend, TritonAttentionImpl,
+                                                TritonAttentionMetadata,
+                                                TritonAttentionMetadataBuilder)
+    B = TritonAttentionBackend
+    assert B.get_name() == "TRITON_ATTN_VLLM_V1" and B.accept_output_buffer
+    assert B.get_impl_cls() is TritonAttentionImpl and B.get_metadata_cls() is TritonAttentionMetadata
+    assert B.get_builder_cls() is TritonAttentionMetadataBuilder
+    assert B.get_kv_cache_shape(10, 16, 8, 128) == (2, 10, 16, 8, 128)
+    with pytest.raises(ValueError, match="multiple of 16"):
+        B.get_kv_cache_shape(10, 8, 8, 128)
+    assert B.use_cascade_attention() is False
+    assert torch.bfloat16 in B.get_supported_dtypes() and 128 in B.get_supported_head_sizes()
+    with pytest.raises(ValueError, match="Head size 256 is not supported by TritonAttention"):
+        B.validate_head_size(256)
+
+    common = types.SimpleNamespace(
+        num_actual_tokens=7, max_query_len=5, query_start_loc=torch.tensor([0, 5, 6, 7], dtype=torch.int32),
+        seq_lens=torch.tensor([9, 30, 2], dtype=torch.int32), seq_lens_cpu=torch.tensor([9, 30, 2], dtype=torch.int32),
+        block_table_tensor=torch.zeros((3, 2), dtype=torch.int32), slot_mapping=torch.arange(7))
+    cfg = types.SimpleNamespace(
+        model_config=types.SimpleNamespace(get_num_attention_heads=lambda pc: 32 // pc.tp,
+                                           get_num_kv_heads=lambda pc: 8 // pc.tp, get_head_size=lambda: 128),
+        parallel_config=types.SimpleNamespace(tp=2))
+    b = TritonAttentionMetadataBuilder(types.SimpleNamespace(block_size=16), cfg, torch.device("cpu"))
+    assert (b.block_size, b.num_heads_q, b.num_heads_kv, b.headdim) == (16, 16, 4, 128)
+    md = b.build(0, common)
+    assert (md.num_actual_tokens, md.max_query_len, md.max_seq_len) == (7, 5, 30)
+    assert md.use_cascade is False and md.cu_prefix_query_lens is None and md.suffix_kv_lens is None
+    assert md.block_table is common.block_table_tensor and md.slot_mapping is common.slot_mapping
+    md = b.build(4, common)   # cascade metadata is built as the reference does (the impl rejects it)
+    assert md.use_cascade and md.prefix_kv_lens.tolist() == [4] and md.suffix_kv_lens.tolist() == [5, 26, -2]
+    assert md.cu_prefix_query_lens.tolist() == [0, 7]
+    md = b.build_for_cudagraph_capture(common)
+    assert md.seq_lens.tolist() == [1, 1, 1] and b.can_run_in_cudagraph(common)
+
+    impl = TritonAttentionImpl(32, 128, 0.25, 8, [0.5] * 32, 1024, "fp8", 30.0)
+    assert impl.sliding_window == (1023, 0) and impl.logits_soft_cap == 30.0 and impl.num_queries_per_kv == 4
+    assert impl.alibi_slopes.dtype == torch.float32 and impl.fp8_dtype == torch.float8_e4m3fn
+    impl = TritonAttentionImpl(32, 64, 0.25, 8, None, None, "auto")
+    assert impl.sliding_window == (-1, -1) and impl.logits_soft_cap == 0 and impl.alibi_slopes is None
+    assert impl.fused_output_quant_supported(torch.float8_e4m3fn, True, (-1, -1))
