@@ -199,6 +199,21 @@ def run_cache_quant(device, iters=20):
         nbytes = T * KVH * D * (2 * 2 + 2 * 1) + 8 * T
         out["reshape_and_cache_fp8_" + name] = dict(us=round(t * 1e6, 2),
                                                     gbps=round(nbytes / t / 1e9, 1))
+    # the V1 engine's cache write: flash layout [NB, BS, KVH, D]
+    for name, T in (("decode_T64", 64), ("prefill_T8192", 8192), ("prefill_T32768", 32768)):
+        KVH, D, BS = 8, 128, 16
+        NB = max(T // BS * 2, 64)
+        k = torch.randn((T, KVH, D), device=device, dtype=torch.bfloat16)
+        v = torch.randn_like(k)
+        kc = torch.zeros((NB, BS, KVH, D), dtype=torch.uint8, device=device)
+        vc = torch.zeros_like(kc)
+        slots = torch.randperm(NB * BS, device=device)[:T].to(torch.int64)
+        sc = torch.tensor([0.05], device=device)
+        fn = lambda: ops.reshape_and_cache_flash(k, v, kc, vc, slots, "fp8", sc, sc)
+        t = time_gpu_graph(fn, iters)
+        nbytes = T * KVH * D * (2 * 2 + 2 * 1) + 8 * T
+        out["reshape_and_cache_flash_fp8_" + name] = dict(us=round(t * 1e6, 2),
+                                                          gbps=round(nbytes / t / 1e9, 1))
     for M, K in ((64, 4096), (4096, 4096), (4096, 14336)):
         x = torch.randn((M, K), device=device, dtype=torch.bfloat16)
         q = torch.empty((M, K), dtype=torch.float8_e4m3fn, device=device)
