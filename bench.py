@@ -387,6 +387,45 @@ def cpu_baseline():
                        f"block 16, bf16 KV; {n} iterations in {el:.1f} s on {used} OpenMP threads")
 
 
+def cpu_baseline_port(budget_s=8.0):
+    """The oracle's C restatement (fp8-capable, unlike the reference's CPU kernel) on a bounded
+    sample of the HEADLINE workload: 8 of the 64 sequences of configs[1] (fp8 KV, ctx 4096)."""
+    from oracle import oracle as O
+    S, ctx, H, KVH, D, BS = 8, 4096, 32, 8, 128, 16
+    g = torch.Generator().manual_seed(0)
+    nb = ctx // BS
+    NB = S * nb
+    kc = torch.randint(0, 120, (NB, KVH, D // 16, BS, 16), generator=g, dtype=torch.uint8)
+    vc = torch.randint(0, 120, (NB, KVH, D, BS), generator=g, dtype=torch.uint8)
+    q = ((torch.rand((S, H, D), generator=g) * 2 - 1) * D ** -0.5).to(torch.bfloat16)
+    bt = torch.randperm(NB, generator=g).to(torch.int32).view(S, nb).contiguous()
+    sl = torch.full((S,), ctx, dtype=torch.int32)
+    out = torch.empty_like(q)
+    fn = lambda: O.paged_attention_v1(out, q, kc, vc, KVH, D ** -0.5, bt, sl, BS, ctx, None, "fp8",
+                                      1.0, 1.0)
+    fn()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        fn()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    per = el / n
+    nbytes = attention_bytes(S, ctx, H, KVH, D, BS, 1)
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count()
+    used = omp if omp > 0 else cores
+    return dict(value=round(nbytes / per / 1e9, 3), unit="GB/s", cores=used, kind="port",
+                ms_per_iter=round(per * 1e3, 1),
+                sample=f"configs[1] shape, 8 of its 64 sequences (fp8 KV, ctx 4096, 32q/8kv, d128, block "
+                       f"16): oracle/oracle.c paged_attention_v1, {n} iterations in {el:.1f} s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -471,6 +510,8 @@ def main():
             extra["prefill_attention"] = run_prefill(device)
             extra["unified_decode"] = run_unified_decode(device)
             line["cpu_baseline"] = cpu_baseline()
+            # same workload as `value` (fp8 KV), which the reference's CPU kernel cannot run
+            line["cpu_baseline_port"] = cpu_baseline_port()
         line["extra"] = extra
     if use_dist:
         from vllm_amd.distributed import bench_row_parallel

@@ -344,6 +344,8 @@ int vllm_amd_unified_attention(
 /*                 registers in flight (not instantiated, measured slower)     */
 /*   "pa_sp":      reference partitions merged per workgroup in v2 / rocm      */
 /*                 launches (0 = heuristic, paged_attention_mfma.hip)          */
+/*   "pa_group":   XCD-grouped workgroup order of the decode kernel (0 = heuristic:   */
+/*                 >= 1024 workgroups and >= 2 kv heads, 1 = always, 2 = never)     */
 /*   "mm_kernel":  scaled_mm kernel for M > 32: 0 = heuristic, 1 = register-   */
 /*                 staged 128x128 tile, 2..10 = direct-to-LDS tile shapes       */
 /*                 (256x256, 128x128, 128x64, 64x64, 64x32; even ids 4..10      */

@@ -58,7 +58,8 @@ def main():
         times = {v: [] for v in variants_}
         for r in range(a.rounds):
             for v in variants_:
-                _lib.set_tuning("pa_variant", v[0])
+                _lib.set_tuning("pa_variant", v[0] & 3)
+                _lib.set_tuning("pa_group", v[0] >> 3)   # + 8: XCD-grouped order always, + 16: never
                 _lib.set_tuning("pa_sp", v[1])
                 _, ev = bench.time_gpu(step, a.iters, 3)
                 times[v].append(ev / a.iters * 1e6)

@@ -41,6 +41,7 @@ int paged_attention_mfma(const PagedAttnParams& p);
 // tuning knob (A/B measurements): see vllm_amd_set_tuning
 void set_pa_variant(int v);
 void set_pa_sp(int v);
+void set_pa_group(int v);
 // Split-K merge of partitions (v2 / rocm).
 int paged_attention_reduce(const PagedAttnParams& p);
 

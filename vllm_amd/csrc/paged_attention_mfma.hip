@@ -67,10 +67,19 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c16 = lane & 15, g4 = lane >> 4;
 
-  // blockIdx.x = ((seq * num_kv_heads + kvh) * gqa_chunks + chunk), blockIdx.y = partition
-  const int chunk = blockIdx.x % gqa_chunks;
-  const int kvh = (blockIdx.x / gqa_chunks) % num_kv_heads;
-  const int seq = blockIdx.x / (gqa_chunks * num_kv_heads);
+  // logical id = ((seq * num_kv_heads + kvh) * gqa_chunks + chunk), blockIdx.y = partition
+  int wg = blockIdx.x;
+  // Large launches: consecutive hardware ids go to different XCDs (id % 8); remapped so that the
+  // kv heads of a sequence -- adjacent pages of the same blocks -- stream through one XCD's L2
+  // (256 sequences x 8 kv heads x 4096 fp8: 330.6 -> 324.6 us; nothing at 512 workgroups)
+  if (slot_stride < 0) {
+    const int nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
+    wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    slot_stride = -slot_stride;
+  }
+  const int chunk = wg % gqa_chunks;
+  const int kvh = (wg / gqa_chunks) % num_kv_heads;
+  const int seq = wg / (gqa_chunks * num_kv_heads);
   const int part = blockIdx.y;
   const int G = num_heads / num_kv_heads;
   const int head0 = kvh * G + chunk * 16;        // first q head of this workgroup
@@ -387,6 +396,8 @@ static int pa_variant() {
 void set_pa_variant(int v) { g_pa_variant = v & 3; }
 static int g_pa_sp = 0;
 void set_pa_sp(int v) { g_pa_sp = v; }
+static int g_pa_group = 0;
+void set_pa_group(int v) { g_pa_group = v; }
 
 template <typename scalar_t, bool FP8, int HS, int BS, int VARIANT>
 static int launch_mfma_v(const PagedAttnParams& p) {
@@ -399,12 +410,14 @@ static int launch_mfma_v(const PagedAttnParams& p) {
   dim3 grid((unsigned)(p.num_seqs * p.num_kv_heads * chunks),
             part ? ceil_div(p.max_num_partitions, sp) : 1);
   void* out = part ? p.tmp_out : p.out;
+  // "pa_group": 0 = heuristic, 1 = always, 2 = never
+  const bool group = g_pa_group == 1 || (g_pa_group == 0 && p.num_kv_heads >= 2 && grid.x >= 1024);
 #define PA_ARGS                                                                                  \
   (scalar_t*)out, p.exp_sums, p.max_logits, (const scalar_t*)p.query,                           \
       (const uint8_t*)p.key_cache, (const uint8_t*)p.value_cache, p.num_heads, p.num_kv_heads,  \
       p.scale, p.block_tables, p.seq_lens, p.query_start_loc, p.max_num_blocks_per_seq,         \
       p.alibi_slopes, p.q_stride, p.kv_block_stride * es, p.kv_head_stride * es, p.k_scale,     \
-      p.v_scale, p.partition_size * sp, p.max_num_partitions, chunks, sp
+      p.v_scale, p.partition_size * sp, p.max_num_partitions, chunks, (group ? -sp : sp)
   hipLaunchKernelGGL((pa_mfma_kernel<scalar_t, FP8, HS, BS, NW, VARIANT>), grid, dim3(NW * 64), 0,
                      p.stream, PA_ARGS);
 #undef PA_ARGS
