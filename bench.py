@@ -319,12 +319,18 @@ def run_unified_decode(device, iters=5):
     from vllm_amd.attention.ops import unified_attention
     H, KVH, D, BS = 32, 8, 128, 16
     out = {}
-    for S, ctx in ((64, 4096), (256, 4096), (16, 16384), (1, 4096)):
+    # hnd: the cache memory is head-major (what TritonAttentionBackend.get_kv_cache_stride_order
+    # asks the engine for by default), passed as a permuted view of the reference's NHD shape
+    for S, ctx, hnd in ((64, 4096, False), (64, 4096, True), (256, 4096, False), (256, 4096, True),
+                        (16, 16384, True), (1, 4096, True)):
         nb = (ctx + BS - 1) // BS
         q = (torch.rand((S, H, D), device=device) - 0.5).to(torch.bfloat16)
         o = torch.empty_like(q)
         kf = torch.randint(0, 120, (S * nb, BS, KVH, D), device=device, dtype=torch.uint8)
         vf = torch.randint(0, 120, (S * nb, BS, KVH, D), device=device, dtype=torch.uint8)
+        if hnd:
+            kf = kf.view(S * nb, KVH, BS, D).permute(0, 2, 1, 3)
+            vf = vf.view(S * nb, KVH, BS, D).permute(0, 2, 1, 3)
         bt = torch.randperm(S * nb, device=device).to(torch.int32).view(S, nb)
         cu = torch.arange(S + 1, device=device, dtype=torch.int32)
         sl = torch.full((S,), ctx, dtype=torch.int32, device=device)
@@ -333,7 +339,7 @@ def run_unified_decode(device, iters=5):
                                        0.0, None, sc, sc)
         t = time_gpu_graph(fn, iters)
         nbytes = 2 * S * ctx * KVH * D + 2 * S * H * D * 2 + S * nb * 4
-        out[f"S{S}_ctx{ctx}_fp8kv"] = dict(us=round(t * 1e6, 1), gbps=round(nbytes / t / 1e9, 1),
+        out[f"S{S}_ctx{ctx}_fp8kv_{'hnd' if hnd else 'nhd'}"] = dict(us=round(t * 1e6, 1), gbps=round(nbytes / t / 1e9, 1),
                                            frac_of_hbm_peak=round(nbytes / t / 1e9 / HBM_PEAK_GBPS, 4))
         del kf, vf
     return out

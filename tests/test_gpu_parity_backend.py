@@ -26,7 +26,7 @@ def _to_x_layout(kc_f, vc_f):
     return kx, vx
 
 
-@pytest.mark.parametrize("path", ["unified", "prefill_decode"])
+@pytest.mark.parametrize("path", ["unified", "unified_nhd", "prefill_decode"])
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("heads", [(8, 2), (32, 8)])
 @pytest.mark.parametrize("mode", ["plain", "alibi", "window", "softcap"])
@@ -36,6 +36,10 @@ def test_triton_attention_impl_forward(oracle, monkeypatch, path, fp8, heads, mo
     from vllm_amd.v1.attention.backends import (TritonAttentionBackend, TritonAttentionImpl,
                                                 TritonAttentionMetadataBuilder)
     monkeypatch.setenv("VLLM_V1_USE_PREFILL_DECODE_ATTENTION", "1" if path == "prefill_decode" else "0")
+    monkeypatch.setenv("VLLM_KV_CACHE_LAYOUT", "NHD" if path == "unified_nhd" else "HND")
+    nhd = path == "unified_nhd"
+    if nhd:
+        path = "unified"
     H, KVH, D, BS, dtype = heads[0], heads[1], 128, 16, torch.bfloat16
     c = make_unified_case(SEQS, H, KVH, D, BS, dtype, fp8=fp8, seed=H + fp8, kv_scale=0.5)
     T = c["q"].shape[0]
@@ -83,8 +87,15 @@ def test_triton_attention_impl_forward(oracle, monkeypatch, path, fp8, heads, mo
     dev = torch.device("cuda", 0)
     impl = TritonAttentionImpl(H, D, D ** -0.5, KVH, slopes, window, kvd, softcap)
     if path == "unified":
-        kv_cache = torch.stack([c["k"], c["v"]]).to(dev)
-        assert kv_cache.shape == TritonAttentionBackend.get_kv_cache_shape(c["k"].shape[0], BS, KVH, D)
+        # allocated as GPUModelRunner._reshape_kv_cache_tensors does (:2699-2726): memory in the
+        # backend's stride order, the logical shape of get_kv_cache_shape as a permuted view
+        shape = TritonAttentionBackend.get_kv_cache_shape(c["k"].shape[0], BS, KVH, D)
+        order = TritonAttentionBackend.get_kv_cache_stride_order()
+        assert order == ((0, 1, 2, 3, 4) if nhd else (0, 1, 3, 2, 4))
+        inv = [order.index(i) for i in range(len(order))]
+        kv_cache = torch.empty([shape[i] for i in order], dtype=c["k"].dtype, device=dev).permute(*inv)
+        assert tuple(kv_cache.shape) == shape and kv_cache.is_contiguous() == nhd
+        kv_cache.copy_(torch.stack([c["k"], c["v"]]))
     else:
         kx, vx = _to_x_layout(c["k"], c["v"])
         kv_cache = torch.stack([kx.reshape(kx.shape[0], -1), vx.reshape(vx.shape[0], -1)]).to(dev)

@@ -144,6 +144,7 @@ def test_v1_backend_host_logic():
     with pytest.raises(ValueError, match="multiple of 16"):
         B.get_kv_cache_shape(10, 8, 8, 128)
     assert B.use_cascade_attention() is False
+    assert B.get_kv_cache_stride_order() == (0, 1, 3, 2, 4)   # head-major memory by default
     assert torch.bfloat16 in B.get_supported_dtypes() and 128 in B.get_supported_head_sizes()
     with pytest.raises(ValueError, match="Head size 256 is not supported by TritonAttention"):
         B.validate_head_size(256)

@@ -12,6 +12,7 @@ ap.add_argument("--kv", default="fp8")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--unified", action="store_true", help="unified_attention over a flash-layout cache")
 ap.add_argument("--rows", type=int, default=0, help="query rows per workgroup (tuning pf_rows)")
+ap.add_argument("--hnd", action="store_true", help="unified: head-major cache memory (permuted view)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 if a.rows:
@@ -48,6 +49,9 @@ for (B, ql, cl) in ((4, 2048, 0), (4, 2048, 2048), (1, 8192, 0), (16, 512, 3584)
         else:
             kf = (torch.rand((B * nb_u, BS, KVH, D), device=dev) - 0.5).to(torch.bfloat16)
             vf = (torch.rand((B * nb_u, BS, KVH, D), device=dev) - 0.5).to(torch.bfloat16)
+        if a.hnd:   # head-major memory behind the NHD shape
+            kf = kf.view(B * nb_u, KVH, BS, D).permute(0, 2, 1, 3)
+            vf = vf.view(B * nb_u, KVH, BS, D).permute(0, 2, 1, 3)
         bt = torch.randperm(B * nb_u, device=dev).to(torch.int32).view(B, nb_u)
         fn = lambda: unified_attention(q, kf, vf, o, start, ql, seql, ql + cl, D ** -0.5, True, (-1, -1),
                                        bt, 0.0, None, one if fp8 else None, one if fp8 else None)
