@@ -82,9 +82,10 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   const int G = p.num_heads / p.num_kv_heads;   // <= 16
   const int head0 = kvh * G;
 
-  const int qtok = p.cu_seqlens_q[seq];
-  if (p.cu_seqlens_q[seq + 1] - qtok != 1) return;   // no query token (the host checked max <= 1)
+  // (all three loads before the first branch: one memory round trip, not two)
   const int seq_len = p.seq_lens[seq];
+  const int qtok = p.cu_seqlens_q[seq], qend = p.cu_seqlens_q[seq + 1];
+  if (qend - qtok != 1) return;   // not a decode token: the tile kernel's (or nobody's) business
   const int ctx = seq_len - 1;                       // position of the query
   const bool split = p.num_segments > 1;
   const int kv_lo = p.window > 0 ? max(0, seq_len - p.window) : 0;   // first visible key
