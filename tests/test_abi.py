@@ -119,6 +119,9 @@ def test_validation_errors_without_launch():
     assert "per-tensor or per-row" in _err(rc)
     assert "batch 5 > 4" in _err(L.vllm_amd_wvSplitKQ(p, p, p, p, p, 64, 128, 5, _lib.BF16, 256, None))
     assert "unknown key" in _err(L.vllm_amd_set_tuning(b"nope", 1))
+    for key, default in ((b"pa_variant", 1), (b"pa_sp", 0), (b"pa_group", 0), (b"mm_kernel", 0), (b"mm_splitk", 0),
+                         (b"pf_rows", 0), (b"uni_decode", 1), (b"cache_runs", 1)):
+        assert L.vllm_amd_set_tuning(key, default) == 0, key   # every documented knob exists
 
 
 def test_torch_layer_rejects_cpu_tensors_and_bad_strings():
