@@ -313,7 +313,7 @@ int vllm_amd_context_attention_fwd(
  *   sliding_window = 1 + window_size[0] of the reference call (0 = none) (:655)
  * Supported here: f16 / bf16 queries (no fp8 queries: q_descale is "not supported" in the
  * reference either, :609), head_size a multiple of 8 (16 with an fp8 cache) up to 128,
- * block_size 16 / 32.  With GQA the tile rows are (token, q head of the group) pairs, so a
+ * block_size any power of two from 16.  With GQA the tile rows are (token, q head of the group) pairs, so a
  * decode token streams its K / V once per group.  Sequences of query length 1 take a dedicated
  * bandwidth kernel (head_size 64 / 128, group <= 16; unified_decode.hip) when the whole launch
  * is decode-only (max_seqlen_q == 1) or has >= 16 sequences; the grid of the tile kernel has

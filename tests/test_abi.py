@@ -187,7 +187,7 @@ def test_validation_errors_of_the_neighbour_ops():
     assert "segment buffers" in _err(ua(nseg=16))
     assert "unsupported head size: 256" in _err(ua(head_size=256))
     assert "unsupported head size: 40" in _err(ua(head_size=40, kv=_lib.KV_FP8_E4M3, qs=320))
-    assert "unsupported block size: 64" in _err(ua(block_size=64))
+    assert "unsupported block size: 48" in _err(ua(block_size=48))
     assert "float16 or bfloat16" in _err(ua(dtype=_lib.F32))
     assert "Unsupported FP8 dtype" in _err(ua(kv=7))
     assert "k_descale and v_descale" in _err(ua(kv=_lib.KV_FP8_E4M3, kd=None))

@@ -75,6 +75,19 @@ def test_unified_fp8_cache(oracle, dtype, block_size, D, soft_cap):
     run(oracle, c, dtype, softcap=soft_cap or 0.0, fp8=True)
 
 
+@pytest.mark.parametrize("block_size", [64, 128])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("seq_lens", [[(1, 1328), (5, 18), (129, 463), (64, 64)], [(1, 523), (1, 37), (1, 2011), (1, 128)],
+                                      [(1, 70)] * 10 + [(40, 300), (1, 129), (1, 1)] * 3])
+def test_unified_large_blocks(oracle, block_size, fp8, seq_lens):
+    """Pages of 64 / 128 tokens (the block size is a run-time power of two in both kernels): mixed,
+    decode-only (split) and >= 16-sequence batches (decode kernel + tile kernel)."""
+    c = make_unified_case(seq_lens, 8, 2, 128, block_size, torch.bfloat16, fp8=fp8, seed=block_size + len(seq_lens),
+                          kv_scale=0.5)
+    run(oracle, c, torch.bfloat16, fp8=fp8)
+    run(oracle, c, torch.bfloat16, fp8=fp8, window=100, softcap=25.0)
+
+
 @pytest.mark.parametrize("D", [32, 80, 96, 120, 128])
 def test_unified_head_sizes(oracle, D):
     c = make_unified_case([(90, 400), (17, 17)], 4, 2, D, 16, torch.bfloat16, seed=D)

@@ -45,6 +45,7 @@ struct PrefillParams {
   // split over the keys (PACK launches with one row block): segment partials, caller-allocated
   float* segm_out; float* segm_max; float* segm_sum;
   int num_segments;     // segments of this launch (1 = no split)
+  int bs_shift;         // UNI: log2(block_size) (any power of two >= 16; the BS template value is unused)
   int flat_batch;       // > 0 = number of sequences: grid.x enumerates the row blocks of all of them,
   int flat_tokens;      //   at most flat_tokens / tokens_per_block + flat_batch (flat_tokens = rows of q)
   int segm_stride;      // segments the buffers were allocated for
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   constexpr int PPT = PF_BN / BS;   // pages per tile
   constexpr int VPG = FP8 ? V8_ITEMS : V16_ITEMS;
   struct Pages { int k; int v[VPG]; };
-  const int last_page = UNI ? (seq_len > 0 ? (seq_len - 1) / BS : 0) : (ctx > 0 ? (ctx - 1) / BS : 0);
+  const int last_page = UNI ? (seq_len > 0 ? (seq_len - 1) >> p.bs_shift : 0) : (ctx > 0 ? (ctx - 1) / BS : 0);
   auto v_page_of_item = [&](int i) {   // page (within the tile) of V item i of this thread
     constexpr int CPP = FP8 ? BS / 16 : BS / 8;
     return min((tid + PF_THREADS * i) / (CPP * D), PPT - 1);
@@ -230,7 +231,8 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   auto load_pages = [&](int t) {
     Pages pg;
     const bool on = UNI ? t < ntiles : t < ctx_tiles;
-    pg.k = on ? bl[min(t * PPT + (tid & 63) / BS, last_page)] : 0;
+    if constexpr (UNI) pg.k = on ? bl[min((t * PF_BN + (tid & 63)) >> p.bs_shift, last_page)] : 0;
+    else pg.k = on ? bl[min(t * PPT + (tid & 63) / BS, last_page)] : 0;
     static_for<VPG>([&](auto ic_) {
       constexpr int i = decltype(ic_)::value;
       pg.v[i] = (on && !UNI) ? bl[min(t * PPT + v_page_of_item(i), last_page)] : 0;
@@ -243,11 +245,11 @@ __global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams
   auto load_tile = [&](int t, const Pages& pg) {
     if constexpr (UNI) {
       // every item of a thread is the same token (PF_THREADS is a multiple of 64): one page
-      const int tok = tid & 63;
+      const int slot = (t * PF_BN + (tid & 63)) & ((1 << p.bs_shift) - 1);
       const uint8_t* krow = p.k_cache + (int64_t)pg.k * p.kc_block_bytes +
-                            (int64_t)(tok % BS) * p.kc_page_bytes + (int64_t)kvh * p.kc_head_bytes;
+                            (int64_t)slot * p.kc_page_bytes + (int64_t)kvh * p.kc_head_bytes;
       const uint8_t* vrow = p.v_cache + (int64_t)pg.k * p.vc_block_bytes +
-                            (int64_t)(tok % BS) * p.vc_page_bytes + (int64_t)kvh * p.vc_head_bytes;
+                            (int64_t)slot * p.vc_page_bytes + (int64_t)kvh * p.vc_head_bytes;
       if constexpr (!FP8) {
         static_for<K16_ITEMS>([&](auto ic_) {
           constexpr int i = decltype(ic_)::value;            // item -> (tok, 8-element chunk)
@@ -739,9 +741,9 @@ static void launch_cfg(const PrefillParams& p, int block_size, int max_input_len
     const int tpb = PACK ? BM / (p.num_heads / p.num_kv_heads) : BM;
     grid = dim3(p.flat_tokens / tpb + p.flat_batch, num_heads, 1);
   }
-  if (block_size == 16)
+  if (UNI || block_size == 16)   // UNI reads the block size from p.bs_shift
     hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 16, MT, NW, UNI, PACK>), grid, dim3(64 * NW), 0, st, p);
-  else
+  else if constexpr (!UNI)
     hipLaunchKernelGGL((prefill_kernel<T, FP8, D, 32, MT, NW, UNI, PACK>), grid, dim3(64 * NW), 0, st, p);
 }
 // unified_attention: padded head sizes 64 and 128 (one configuration each)
@@ -817,16 +819,16 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
     } else {
       p.num_segments = 1;
     }
-    if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true, true>(p, block_size, rows, p.num_kv_heads, batch, st);
-    else launch_cfg<T, FP8, 128, 1, 4, true, true>(p, block_size, rows, p.num_kv_heads, batch, st);
+    if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true, true>(p, 16, rows, p.num_kv_heads, batch, st);
+    else launch_cfg<T, FP8, 128, 1, 4, true, true>(p, 16, rows, p.num_kv_heads, batch, st);
     if (p.num_segments > 1)
       hipLaunchKernelGGL((unified_reduce_kernel<T>), dim3(num_tokens, num_heads), dim3(64), 0, st, p, tpb,
                          batch);
     return VLLM_AMD_OK;
   }
   p.num_segments = 1;
-  if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true>(p, block_size, max_q, num_heads, batch, st);
-  else launch_cfg<T, FP8, 128, 1, 4, true>(p, block_size, max_q, num_heads, batch, st);
+  if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true>(p, 16, max_q, num_heads, batch, st);
+  else launch_cfg<T, FP8, 128, 1, 4, true>(p, 16, max_q, num_heads, batch, st);
   return VLLM_AMD_OK;
 }
 template <typename T, bool FP8, int D>
@@ -916,6 +918,7 @@ extern "C" int vllm_amd_context_attention_fwd(
   p.softcap = 0.f;
   p.segm_out = p.segm_max = p.segm_sum = nullptr;
   p.num_segments = p.segm_stride = 1;
+  p.bs_shift = 0;
   p.flat_batch = num_tokens > 0 ? batch : 0;
   p.flat_tokens = num_tokens;
   hipStream_t st = (hipStream_t)stream;
@@ -957,8 +960,8 @@ extern "C" int vllm_amd_unified_attention(
              VLLM_AMD_EUNSUPPORTED,
              "%s: unsupported head size: %d (multiples of 8, of 16 with an fp8 cache, up to 128)",
              op, head_size);
-  VA_REQUIRE(block_size == 16 || block_size == 32, VLLM_AMD_EUNSUPPORTED,
-             "%s: unsupported block size: %d (16, 32)", op, block_size);
+  VA_REQUIRE(block_size >= 16 && (block_size & (block_size - 1)) == 0, VLLM_AMD_EUNSUPPORTED,
+             "%s: unsupported block size: %d (powers of two from 16)", op, block_size);
   VA_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, VLLM_AMD_EINVAL,
              "%s: num_heads must be a multiple of num_kv_heads", op);
   VA_REQUIRE(es == 2 || (k_descale && v_descale), VLLM_AMD_EINVAL,
@@ -1001,6 +1004,8 @@ extern "C" int vllm_amd_unified_attention(
   p.segm_stride = p.num_segments;
   // one grid entry per row block of any sequence (launch_cfg) when the caller says how many
   // query tokens there are
+  p.bs_shift = 0;
+  while ((1 << p.bs_shift) < block_size) ++p.bs_shift;
   p.flat_batch = num_tokens > 0 ? num_seqs : 0;
   p.flat_tokens = num_tokens;
   hipStream_t st = (hipStream_t)stream;
