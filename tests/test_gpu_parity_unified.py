@@ -151,6 +151,23 @@ def test_unified_decode_kernel(oracle, dtype, block_size, fp8, nseq):
     run(oracle, c, dtype, fp8=fp8)
 
 
+@pytest.mark.parametrize("D", [32, 48, 80, 96, 112, 120])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("nseq", [5, 260])
+def test_unified_decode_head_sizes(oracle, D, fp8, nseq):
+    """Head sizes below the kernel's padded 64 / 128 (whole 16-byte K chunks): split and unsplit
+    launches, and a mixed batch of >= 16 sequences."""
+    if fp8 and D % 16:
+        pytest.skip("an fp8 cache needs head sizes that are multiples of 16")
+    lens = [1, 31, 64, 65, 129, 300, 700]
+    seqs = [(1, lens[i % len(lens)] + i // 7) for i in range(nseq)]
+    c = make_unified_case(seqs, 8, 4, D, 16, torch.bfloat16, fp8=fp8, seed=D + nseq, kv_scale=0.5)
+    run(oracle, c, torch.bfloat16, fp8=fp8)
+    if nseq == 5:
+        c = make_unified_case(seqs * 4 + [(37, 120)], 8, 4, D, 16, torch.bfloat16, fp8=fp8, seed=D, kv_scale=0.5)
+        run(oracle, c, torch.bfloat16, fp8=fp8, window=90)
+
+
 @pytest.mark.parametrize("mode", ["window", "alibi", "softcap", "fp8_out", "hnd"])
 @pytest.mark.parametrize("fp8", [False, True])
 def test_unified_decode_kernel_features(oracle, mode, fp8):

@@ -81,6 +81,9 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   const int seg = blockIdx.y;
   const int G = p.num_heads / p.num_kv_heads;   // <= 16
   const int head0 = kvh * G;
+  // D = head size padded to 64 / 128: chunks at d >= dr are never loaded (zeros: no contribution to
+  // the scores, output columns that are never stored)
+  const int dr = p.head_size;
 
   // (all three loads before the first branch: one memory round trip, not two)
   const int seq_len = p.seq_lens[seq];
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
       int d;
       if constexpr (FP8) d = 16 * (g4 + 4 * (s >> 1)) + 8 * (s & 1);
       else d = 8 * (g4 + 4 * s);
-      qf[s] = col_ok ? *reinterpret_cast<const uint4*>(qp + d) : make_uint4(0, 0, 0, 0);
+      qf[s] = (col_ok && d < dr) ? *reinterpret_cast<const uint4*>(qp + d) : make_uint4(0, 0, 0, 0);
     }
   }
 
@@ -149,15 +152,19 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   constexpr int RB = D * ES, CPR = RB / 16, RPI = 64 / CPR;   // row bytes, chunks per row, rows per instruction
   auto kswz = [](int row) { return (row * CPR / 16) & (CPR - 1); };
   uint32_t koff[KL], krd[KL];
+  bool kval[KL];   // the chunk this lane fetches exists (head sizes below the padded D)
 #pragma unroll
   for (int i = 0; i < KL; ++i) {
     const int row = i * RPI + lane / CPR;
-    koff[i] = (uint32_t)(row * p.kc_slot_bytes + (((lane % CPR) ^ kswz(row)) << 4));
+    const int chunk = (lane % CPR) ^ kswz(row);
+    kval[i] = chunk * 16 < dr * ES;
+    koff[i] = (uint32_t)(row * p.kc_slot_bytes + (chunk << 4));
     krd[i] = (uint32_t)(c16 * RB + (((g4 + 4 * i) ^ kswz(c16)) << 4));
   }
   uint32_t voff[4];   // row r of the lane's four tokens of a tile
 #pragma unroll
   for (int r = 0; r < 4; ++r) voff[r] = (uint32_t)((4 * g4 + r) * p.vc_slot_bytes + c16 * (DT * ES));
+  const bool vval = c16 * DT < dr;   // this lane's d elements exist
   const uint8_t* const k_head = p.k_cache + (int64_t)kvh * p.kc_head_bytes;
   const uint8_t* const v_head = p.v_cache + (int64_t)kvh * p.vc_head_bytes;
 
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
       const uint8_t* base = k_head + (int64_t)pb[t] * p.kc_block_bytes +
                             (int64_t)(((tile0 + t) & sub_mask) * 16) * p.kc_slot_bytes;
 #pragma unroll
-      for (int i = 0; i < KL; ++i) kreg[t * KL + i] = nt_load<4>(base + ko[i]);
+      for (int i = 0; i < KL; ++i) kreg[t * KL + i] = kval[i] ? nt_load<4>(base + ko[i]) : (u32x4)(0);
     }
   };
   auto issue_v = [&](int step) {
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
       const uint8_t* base = v_head + (int64_t)pb[t] * p.vc_block_bytes +
                             (int64_t)(((tile0 + t) & sub_mask) * 16) * p.vc_slot_bytes;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) vreg[t * 4 + r] = nt_load<VDW>(base + vo[r]);
+      for (int r = 0; r < 4; ++r) vreg[t * 4 + r] = vval ? nt_load<VDW>(base + vo[r]) : (vrow_t)(0);
     }
   };
 
@@ -352,7 +359,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   // thread -> (q head qh, 8 consecutive d)
   constexpr int TPH = D / 8;
   const int qh = threadIdx.x / TPH, d0 = (threadIdx.x % TPH) * 8;
-  if (qh >= G) return;
+  if (qh >= G || d0 >= dr) return;
   float mt = -FLT_MAX;
 #pragma unroll
   for (int w = 0; w < NW; ++w) mt = fmaxf(mt, ml[(w * 16 + qh) * 2]);
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   if (split) {
     // unnormalised partial (v_scale applied), running max in the log2 domain, sum
     const int64_t row = ((int64_t)qtok * p.num_heads + head) * p.segm_stride + seg;
-    float* so = p.segm_out + row * D + d0;
+    float* so = p.segm_out + row * dr + d0;
     *reinterpret_cast<f32x4*>(so) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
     *reinterpret_cast<f32x4*>(so + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
     if (d0 == 0) {
@@ -416,6 +423,8 @@ __global__ __launch_bounds__(256) void ua_decode_reduce_kernel(const UniDecodePa
   float acc[VPL], l = 0.f;
 #pragma unroll
   for (int j = 0; j < VPL; ++j) acc[j] = 0.f;
+  const int dr = p.head_size;
+  const bool dval = VPL * lane < dr;
   if (nseg > 0) {
     const float ms = lane < nseg ? p.segm_max[row + lane] : -INFINITY;
     const float ls = lane < nseg ? p.segm_sum[row + lane] : 0.f;
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(256) void ua_decode_reduce_kernel(const UniDecodePa
     fv part[16];
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2)
-      part[s2] = *reinterpret_cast<const fv*>(p.segm_out + (row + min(s2, nseg - 1)) * D + VPL * lane);
+      part[s2] = dval ? *reinterpret_cast<const fv*>(p.segm_out + (row + min(s2, nseg - 1)) * dr + VPL * lane) : (fv)(0.f);
     float mx = ms;
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
@@ -439,6 +448,7 @@ __global__ __launch_bounds__(256) void ua_decode_reduce_kernel(const UniDecodePa
       for (int j = 0; j < VPL; ++j) acc[j] += part[s2][j] * ws;
     }
   }
+  if (!dval) return;
   const float inv = l > 0.f ? 1.0f / l : 0.f;
   const int64_t oidx = (int64_t)qtok * p.o_stride_t + (int64_t)head * p.o_stride_h + VPL * lane;
   if (p.out_scale) {
@@ -471,11 +481,12 @@ int launch(const UniDecodeParams& p) {
 }  // namespace
 
 bool unified_decode_supported(const UniDecodeParams& p) {
-  if (p.head_size != 128 && p.head_size != 64) return false;
+  // head sizes up to 128 in whole 16-byte K chunks and 8-element output pieces (padded to 64 / 128)
+  if (p.head_size < 8 || p.head_size > 128 || p.head_size % (p.fp8 ? 16 : 8) != 0) return false;
   if (p.block_size < 16 || (p.block_size & (p.block_size - 1)) != 0) return false;
   if (p.num_kv_heads <= 0 || p.num_heads % p.num_kv_heads != 0 || p.num_heads / p.num_kv_heads > 16) return false;
   const int es = p.fp8 ? 1 : 2;
-  const int vrow = p.head_size / 16 * es;   // bytes of a V row one lane loads (4, 8 or 16)
+  const int vrow = (p.head_size <= 64 ? 4 : 8) * es;   // bytes of a V row one lane loads (4, 8 or 16)
   if (p.vc_slot_bytes % vrow || p.vc_block_bytes % vrow || p.vc_head_bytes % vrow) return false;
   if (p.kc_slot_bytes % 16 || p.kc_block_bytes % 16 || p.kc_head_bytes % 16) return false;
   if (p.q_stride_t % 8 || p.q_stride_h % 8 || (((uintptr_t)p.q) & 15)) return false;
@@ -487,7 +498,7 @@ bool unified_decode_supported(const UniDecodeParams& p) {
 
 int unified_decode(const UniDecodeParams& p) {
 #define L(T) \
-  (p.head_size == 128 ? (p.fp8 ? launch<T, true, 128>(p) : launch<T, false, 128>(p)) \
+  (p.head_size > 64 ? (p.fp8 ? launch<T, true, 128>(p) : launch<T, false, 128>(p)) \
                       : (p.fp8 ? launch<T, true, 64>(p) : launch<T, false, 64>(p)))
   return p.dtype == VLLM_AMD_F16 ? L(f16_t) : L(bf16_t);
 #undef L
