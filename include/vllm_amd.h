@@ -315,7 +315,7 @@ int vllm_amd_context_attention_fwd(
  * reference either, :609), head_size a multiple of 8 (16 with an fp8 cache) up to 128,
  * block_size any power of two from 16.  With GQA the tile rows are (token, q head of the group) pairs, so a
  * decode token streams its K / V once per group.  Sequences of query length 1 take a dedicated
- * bandwidth kernel (any supported head_size, group <= 16; unified_decode.hip) when the whole launch
+ * bandwidth kernel (unified_decode.hip) when the whole launch
  * is decode-only (max_seqlen_q == 1) or has >= 16 sequences; the grid of the tile kernel has
  * one entry per row block of any sequence when num_tokens is given (> 0).
  *   num_tokens = rows of q (total query tokens of the launch); max_seqlen_k >= every seqused_k

@@ -168,6 +168,19 @@ def test_unified_decode_head_sizes(oracle, D, fp8, nseq):
         run(oracle, c, torch.bfloat16, fp8=fp8, window=90)
 
 
+@pytest.mark.parametrize("heads", [(32, 1), (48, 2), (20, 1), (17, 1)])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("nseq", [4, 600])
+def test_unified_decode_wide_groups(oracle, heads, fp8, nseq):
+    """GQA groups of more than 16 q heads (MQA): 16 heads per workgroup, the last chunk partial;
+    split and unsplit launches, ALiBi per head."""
+    lens = [1, 33, 64, 130, 500]
+    seqs = [(1, lens[i % len(lens)] + i // 5) for i in range(nseq)]
+    c = make_unified_case(seqs, heads[0], heads[1], 64, 16, torch.float16, fp8=fp8, seed=heads[0] + nseq, kv_scale=0.5)
+    slopes = 2.0 ** -(torch.arange(heads[0]).float() * 0.125 + 1)
+    run(oracle, c, torch.float16, fp8=fp8, alibi=slopes)
+
+
 @pytest.mark.parametrize("mode", ["window", "alibi", "softcap", "fp8_out", "hnd"])
 @pytest.mark.parametrize("fp8", [False, True])
 def test_unified_decode_kernel_features(oracle, mode, fp8):
@@ -185,7 +198,7 @@ def test_unified_decode_kernel_features(oracle, mode, fp8):
         out_scale=torch.tensor([0.02]) if mode == "fp8_out" else None, view=view)
 
 
-@pytest.mark.parametrize("heads", [(8, 2), (32, 8), (4, 4)])
+@pytest.mark.parametrize("heads", [(8, 2), (32, 8), (4, 4), (24, 1)])
 @pytest.mark.parametrize("D", [128, 64])
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("mode", ["plain", "window", "alibi", "softcap"])

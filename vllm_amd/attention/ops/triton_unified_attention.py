@@ -46,7 +46,7 @@ def unified_attention(q, k, v, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_s
     segm_out = segm_max = segm_sum = None
     nseg = 0
     num_kv_heads = k.shape[2]
-    if max_seqlen_q == 1 and num_seqs * num_kv_heads < 1024:
+    if max_seqlen_q == 1 and num_seqs * num_kv_heads * ((q.shape[1] // num_kv_heads + 15) // 16) < 1024:
         nseg = 16
         segm_out = torch.empty((q.shape[0], q.shape[1], nseg, q.shape[2]), dtype=torch.float32,
                                device=q.device)

@@ -782,7 +782,7 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
     // rounds instead of 2); few sequences: as many segments of >= 256 tokens as allowed.
     int nseg = 1;
     if (p.num_segments > 1 && !mixed) {
-      const int wgs = batch * p.num_kv_heads;
+      const int wgs = batch * p.num_kv_heads * ((gqa + 15) / 16);
       int cap = (max_k + 4 * PF_BN - 1) / (4 * PF_BN);
       if (cap > p.num_segments) cap = p.num_segments;
       if (cap > 16) cap = 16;

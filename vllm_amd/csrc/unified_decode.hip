@@ -3,8 +3,8 @@
 // V1 engine (vllm/attention/ops/triton_unified_attention.py:52-272 for the maths; caller
 // vllm/v1/attention/backends/triton_attn.py:297-317).
 //
-// One workgroup (4 waves) per (sequence, kv head[, key segment]) serves the whole GQA group, so
-// every K / V byte is read once.  Waves stride over steps of 16 KiB of KV (fp8: 64 tokens,
+// One workgroup (4 waves) per (sequence, kv head[, key segment]) serves the whole GQA group (16 q
+// heads of it at a time), so every K / V byte is read once.  Waves stride over steps of 16 KiB of KV (fp8: 64 tokens,
 // 16-bit: 32), each with a private online softmax; one merge through LDS at the end.
 //
 //   K  a token's row is d-contiguous -- the A-operand order of S^T = K Q^T -- but a lane of the
@@ -77,10 +77,14 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
     const int nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
     wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
-  const int kvh = wg % p.num_kv_heads, seq = wg / p.num_kv_heads;
+  // GQA groups of more than 16 q heads (MQA models) take ceil(G / 16) workgroups per kv head,
+  // chunk fastest: the chunks re-read the same K / V, through L2 when they run together
+  const int Gall = p.num_heads / p.num_kv_heads;
+  const int chunks = (Gall + 15) >> 4;
+  const int chunk = wg % chunks, kvh = (wg / chunks) % p.num_kv_heads, seq = wg / (chunks * p.num_kv_heads);
   const int seg = blockIdx.y;
-  const int G = p.num_heads / p.num_kv_heads;   // <= 16
-  const int head0 = kvh * G;
+  const int G = min(16, Gall - 16 * chunk);   // q heads of this workgroup
+  const int head0 = kvh * Gall + 16 * chunk;
   // D = head size padded to 64 / 128: chunks at d >= dr are never loaded (zeros: no contribution to
   // the scores, output columns that are never stored)
   const int dr = p.head_size;
@@ -466,7 +470,8 @@ int launch(const UniDecodeParams& p) {
   constexpr int NW = 4;
   int sub_shift = 0;
   while ((16 << sub_shift) < p.block_size) ++sub_shift;
-  const dim3 grid((unsigned)(p.num_seqs * p.num_kv_heads), (unsigned)(p.num_segments > 1 ? p.num_segments : 1));
+  const int chunks = (p.num_heads / p.num_kv_heads + 15) / 16;
+  const dim3 grid((unsigned)(p.num_seqs * p.num_kv_heads * chunks), (unsigned)(p.num_segments > 1 ? p.num_segments : 1));
   hipLaunchKernelGGL((ua_decode_kernel<T, FP8, D, NW>), grid, dim3(NW * 64), 0, p.stream, p, sub_shift,
                      g_uni_decode == 2 ? 1 : g_uni_decode == 3 ? 0 : (grid.x * grid.y >= 1024 ? 1 : 0));
   VA_LAUNCH_CHECK("unified_attention decode launch");
@@ -484,7 +489,7 @@ bool unified_decode_supported(const UniDecodeParams& p) {
   // head sizes up to 128 in whole 16-byte K chunks and 8-element output pieces (padded to 64 / 128)
   if (p.head_size < 8 || p.head_size > 128 || p.head_size % (p.fp8 ? 16 : 8) != 0) return false;
   if (p.block_size < 16 || (p.block_size & (p.block_size - 1)) != 0) return false;
-  if (p.num_kv_heads <= 0 || p.num_heads % p.num_kv_heads != 0 || p.num_heads / p.num_kv_heads > 16) return false;
+  if (p.num_kv_heads <= 0 || p.num_heads % p.num_kv_heads != 0) return false;
   const int es = p.fp8 ? 1 : 2;
   const int vrow = (p.head_size <= 64 ? 4 : 8) * es;   // bytes of a V row one lane loads (4, 8 or 16)
   if (p.vc_slot_bytes % vrow || p.vc_block_bytes % vrow || p.vc_head_bytes % vrow) return false;
