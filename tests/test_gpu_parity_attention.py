@@ -100,6 +100,20 @@ def test_generic_path(ops, oracle, version, kv, dtype, hs_bs):
     run_case(ops, oracle, c, version)
 
 
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("hs_bs", [(32, 32), (80, 32), (96, 16), (112, 32), (120, 16)])
+def test_mfma_padded_head_sizes(ops, oracle, version, kv, hs_bs):
+    """head sizes below 64 / 128 run the MFMA kernel padded (absent chunks never loaded);
+    GQA 4:1 and contexts past one partition (reference HEAD_SIZES, test_attention.py:33)."""
+    hs, bs = hs_bs
+    if kv != "auto" and hs % 16:
+        pytest.skip("fp8 cache needs head_size % 16 == 0 (x = 16), as in the reference tests")
+    c = make_attn_case(6, 16, 4, hs, bs, torch.bfloat16, kv, [1, 17, 64, 513, 1100, 2050], seed=hs,
+                       kv_scale=1.0 if kv == "auto" else 0.5, alibi=(hs == 96))
+    run_case(ops, oracle, c, version)
+
+
 @pytest.mark.parametrize("version", ["v1", "v2", "rocm"])
 def test_alibi_gqa(ops, oracle, version):
     c = make_attn_case(4, 64, 8, 128, 16, torch.bfloat16, "fp8", [5, 100, 777, 2049], seed=11,

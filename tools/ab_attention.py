@@ -18,6 +18,8 @@ CFGS = {
     "C2bf16": dict(S=64, ctx=4096, H=32, KVH=8, D=128, BS=16, kv="auto"),
     "C4": dict(S=256, ctx=32768, H=8, KVH=1, D=128, BS=16, kv="fp8"),
     "C5": dict(S=8, ctx=131072, H=64, KVH=8, D=128, BS=16, kv="fp8"),
+    "C2d96": dict(S=64, ctx=4096, H=32, KVH=8, D=96, BS=16, kv="fp8"),   # padded head size
+    "C2d80bf16": dict(S=64, ctx=4096, H=32, KVH=8, D=80, BS=16, kv="auto"),
     "C5tp8": dict(S=8, ctx=131072, H=8, KVH=1, D=128, BS=16, kv="fp8"),
 }
 

@@ -43,7 +43,10 @@ constexpr int kPRowBytes = 144;  // P tile row (one q head): 64 tok * 2 B + 16 B
 // Partitioned launches (v2 / rocm): blockIdx.y = super-partition of `slot_stride` reference
 // partitions (partition_size = its token count); the partial result goes to scratch slot
 // blockIdx.y * slot_stride, the slots in between are not used (see launch_mfma_v).
-template <typename scalar_t, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int NW, int VARIANT>
+// PAD: the real head size `dr` is below HEAD_SIZE (a multiple of 8, of 16 with an fp8 cache): d
+// chunks / rows at d >= dr do not exist in the cache and are never loaded (zeros), output columns
+// there are never stored.
+template <typename scalar_t, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int NW, int VARIANT, bool PAD>
 __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
     scalar_t* __restrict__ out, float* __restrict__ exp_sums, float* __restrict__ max_logits,
     const scalar_t* __restrict__ q, const uint8_t* __restrict__ k_cache,
@@ -53,7 +56,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
     const float* __restrict__ alibi_slopes, int64_t q_stride, int64_t kv_block_bytes,
     int64_t kv_head_bytes, const float* __restrict__ k_scale_p,
     const float* __restrict__ v_scale_p, int partition_size, int max_parts, int gqa_chunks,
-    int slot_stride) {
+    int slot_stride, int dr_arg) {
+  const int dr = PAD ? dr_arg : HEAD_SIZE;
   constexpr int ES = FP8 ? 1 : 2;             // cache element bytes
   constexpr int TILES = FP8 ? 4 : 2;          // 16-token tiles per step
   constexpr int STEP_TOK = TILES * 16;
@@ -118,13 +122,13 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
   constexpr int QF = HEAD_SIZE / 32;  // k-steps of the QK product
   uint4 qf[QF];
   {
-    const scalar_t* qp = q + qrow * q_stride + (int64_t)(head0 + c16) * HEAD_SIZE;
+    const scalar_t* qp = q + qrow * q_stride + (int64_t)(head0 + c16) * dr;
 #pragma unroll
     for (int s = 0; s < QF; ++s) {
       int d;
       if constexpr (FP8) d = 16 * (g4 + 4 * (s >> 1)) + 8 * (s & 1);
       else d = 8 * (g4 + 4 * s);
-      qf[s] = col_ok ? *reinterpret_cast<const uint4*>(qp + d) : make_uint4(0, 0, 0, 0);
+      qf[s] = (col_ok && (!PAD || d < dr)) ? *reinterpret_cast<const uint4*>(qp + d) : make_uint4(0, 0, 0, 0);
     }
   }
 
@@ -164,7 +168,9 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
                             (tile % SUBS) * 256;
 #pragma unroll
       for (int i = 0; i < KL; ++i)
-        kreg[t * KL + i] = ld16(base + (g4 + 4 * i) * K_CHUNK_BYTES + c16 * 16);
+        kreg[t * KL + i] = (!PAD || (g4 + 4 * i) * 16 < dr * ES)
+                               ? ld16(base + (g4 + 4 * i) * K_CHUNK_BYTES + c16 * 16)
+                               : make_uint4(0, 0, 0, 0);
     }
   };
   auto issue_v = [&](VRegs& vreg, int step) {
@@ -184,7 +190,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
                           (FP8 ? 0 : (g4 & 1) * 16);
 #pragma unroll
     for (int m = 0; m < DT; ++m)
-      vreg[m] = ld16(base + (16 * m + c16) * V_ROW_BYTES);
+      vreg[m] = (!PAD || 16 * m + c16 < dr) ? ld16(base + (16 * m + c16) * V_ROW_BYTES)
+                                            : make_uint4(0, 0, 0, 0);
   };
 
   // one step of the online-softmax recurrence on the registers of (kreg, vreg);
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
   constexpr int TPH = HEAD_SIZE / 8;             // threads per head row
   const int qh = threadIdx.x / TPH;
   const int d0 = (threadIdx.x % TPH) * 8;
-  if (qh < nheads) {
+  if (qh < nheads && (!PAD || d0 < dr)) {
     // l_tot / m_tot of column qh live in lanes with c16 == qh; recompute from LDS
     float mt = -FLT_MAX;
 #pragma unroll
@@ -356,13 +363,13 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
     int64_t oidx;
     if (partitioned) {
       const int64_t sidx = ((int64_t)seq * num_heads + head) * max_parts + (int64_t)part * slot_stride;
-      oidx = sidx * HEAD_SIZE + d0;
+      oidx = sidx * dr + d0;
       if (d0 == 0) {
         max_logits[sidx] = mt * kLn2;
         exp_sums[sidx] = lt;
       }
     } else {
-      oidx = ((int64_t)qrow * num_heads + head) * HEAD_SIZE + d0;
+      oidx = ((int64_t)qrow * num_heads + head) * dr + d0;
     }
     *reinterpret_cast<uint4*>(out + oidx) = pk;
   }
@@ -371,7 +378,10 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
 // ------------------------------------------------------------------------------------
 bool paged_attention_mfma_supported(const PagedAttnParams& p) {
   if (p.dtype != VLLM_AMD_F16 && p.dtype != VLLM_AMD_BF16) return false;
-  if (p.head_size != 128 && p.head_size != 64) return false;
+  // head sizes up to 128 in whole 16-byte chunks of K and of the output (padded to 64 / 128)
+  if (p.head_size < 16 || p.head_size > 128 ||
+      p.head_size % (p.kv_dtype == VLLM_AMD_KV_AUTO ? 8 : 16) != 0)
+    return false;
   if (p.block_size != 16 && p.block_size != 32) return false;
   if (p.bs_vert_stride > 1) return false;                 // block-sparse -> generic
   if (p.partition_size > 0 && p.partition_size % 64 != 0) return false;
@@ -399,7 +409,7 @@ void set_pa_sp(int v) { g_pa_sp = v; }
 static int g_pa_group = 0;
 void set_pa_group(int v) { g_pa_group = v; }
 
-template <typename scalar_t, bool FP8, int HS, int BS, int VARIANT>
+template <typename scalar_t, bool FP8, int HS, int BS, int VARIANT, bool PAD>
 static int launch_mfma_v(const PagedAttnParams& p) {
   constexpr int NW = 4;
   const int G = p.num_heads / p.num_kv_heads;
@@ -417,8 +427,8 @@ static int launch_mfma_v(const PagedAttnParams& p) {
       (const uint8_t*)p.key_cache, (const uint8_t*)p.value_cache, p.num_heads, p.num_kv_heads,  \
       p.scale, p.block_tables, p.seq_lens, p.query_start_loc, p.max_num_blocks_per_seq,         \
       p.alibi_slopes, p.q_stride, p.kv_block_stride * es, p.kv_head_stride * es, p.k_scale,     \
-      p.v_scale, p.partition_size * sp, p.max_num_partitions, chunks, (group ? -sp : sp)
-  hipLaunchKernelGGL((pa_mfma_kernel<scalar_t, FP8, HS, BS, NW, VARIANT>), grid, dim3(NW * 64), 0,
+      p.v_scale, p.partition_size * sp, p.max_num_partitions, chunks, (group ? -sp : sp), p.head_size
+  hipLaunchKernelGGL((pa_mfma_kernel<scalar_t, FP8, HS, BS, NW, VARIANT, PAD>), grid, dim3(NW * 64), 0,
                      p.stream, PA_ARGS);
 #undef PA_ARGS
   VA_LAUNCH_CHECK("paged_attention mfma launch");
@@ -428,22 +438,24 @@ static int launch_mfma_v(const PagedAttnParams& p) {
 
 template <typename scalar_t, bool FP8, int HS, int BS>
 static int launch_mfma(const PagedAttnParams& p) {
-  switch (pa_variant()) {
-    // bit 1 (two register sets in flight) measured 1% slower than bit 0 alone on
-    // configs[1] (profiles/r01_ab_attention.txt) and is not instantiated
-    case 0: case 2: return launch_mfma_v<scalar_t, FP8, HS, BS, 0>(p);
-    default: return launch_mfma_v<scalar_t, FP8, HS, BS, 1>(p);
-  }
+  // bit 1 (two register sets in flight) measured 1% slower than bit 0 alone on
+  // configs[1] (profiles/r01_ab_attention.txt) and is not instantiated
+  const bool nt = (pa_variant() & 1) != 0;
+  if (p.head_size != HS)   // padded head sizes: non-temporal loads only
+    return launch_mfma_v<scalar_t, FP8, HS, BS, 1, true>(p);
+  return nt ? launch_mfma_v<scalar_t, FP8, HS, BS, 1, false>(p)
+            : launch_mfma_v<scalar_t, FP8, HS, BS, 0, false>(p);
 }
 
 template <typename scalar_t>
 static int dispatch_mfma(const PagedAttnParams& p) {
   const bool fp8 = p.kv_dtype == VLLM_AMD_KV_FP8_E4M3;
+  const int hs = p.head_size <= 64 ? 64 : 128;   // padded
 #define L(HS, BS) return fp8 ? launch_mfma<scalar_t, true, HS, BS>(p) : launch_mfma<scalar_t, false, HS, BS>(p)
-  if (p.head_size == 128 && p.block_size == 16) L(128, 16);
-  if (p.head_size == 128 && p.block_size == 32) L(128, 32);
-  if (p.head_size == 64 && p.block_size == 16) L(64, 16);
-  if (p.head_size == 64 && p.block_size == 32) L(64, 32);
+  if (hs == 128 && p.block_size == 16) L(128, 16);
+  if (hs == 128 && p.block_size == 32) L(128, 32);
+  if (hs == 64 && p.block_size == 16) L(64, 16);
+  if (hs == 64 && p.block_size == 32) L(64, 32);
 #undef L
   VA_REQUIRE(false, VLLM_AMD_EUNSUPPORTED, "paged_attention mfma: unsupported shape");
 }
