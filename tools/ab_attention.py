@@ -20,6 +20,12 @@ CFGS = {
     "C5": dict(S=8, ctx=131072, H=64, KVH=8, D=128, BS=16, kv="fp8"),
     "C2d96": dict(S=64, ctx=4096, H=32, KVH=8, D=96, BS=16, kv="fp8"),   # padded head size
     "C2d80bf16": dict(S=64, ctx=4096, H=32, KVH=8, D=80, BS=16, kv="auto"),
+    "S20": dict(S=20, ctx=4096, H=32, KVH=8, D=128, BS=16, kv="fp8"),   # v1 by the reference's rule, < 512 workgroups
+    "S32": dict(S=32, ctx=4096, H=32, KVH=8, D=128, BS=16, kv="fp8"),
+    "S48": dict(S=48, ctx=4096, H=32, KVH=8, D=128, BS=16, kv="fp8"),
+    "S32d": dict(S=32, ctx=8192, H=32, KVH=8, D=128, BS=16, kv="fp8"),
+    "S32h": dict(S=32, ctx=1024, H=32, KVH=8, D=128, BS=16, kv="fp8"),
+    "S48bf16": dict(S=48, ctx=4096, H=32, KVH=8, D=128, BS=16, kv="auto"),
     "C5tp8": dict(S=8, ctx=131072, H=8, KVH=1, D=128, BS=16, kv="fp8"),
 }
 
