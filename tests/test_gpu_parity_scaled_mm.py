@@ -141,6 +141,29 @@ def test_scaled_mm_large_auto(ops):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("MN", [(4096, 6144), (4000, 6144), (3584, 6144), (3500, 6144), (2048, 10240), (4096, 4096)])
+@pytest.mark.parametrize("per_channel", [True, False])
+def test_scaled_mm_tail_round_split(ops, MN, per_channel):
+    """Shapes whose 256 x 256 tiles end in a round that covers at most half the CUs run as two
+    launches (the tail columns with 128 x 128 tiles, scaled_mm.hip): small-integer operands and
+    power-of-two scales make every sum exact, so the result equals the fp32 matmul bit for bit,
+    in both column ranges, with per-channel scales and bias addressed past the seam."""
+    M, N = MN
+    K = 384
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    w[:, 0] = torch.arange(N).float() % 7                    # column identity
+    sa = (2.0 ** -(torch.arange(M) % 3).float()).reshape(M, 1)
+    sb = (2.0 ** -(torch.arange(N) % 4).float()).reshape(N, 1) if per_channel else torch.full((1, 1), 0.5)
+    bias = (torch.arange(N) % 9).to(torch.bfloat16)
+    out = ops.cutlass_scaled_mm(a.to(torch.float8_e4m3fn).cuda(), w.to(torch.float8_e4m3fn).cuda().t(),
+                                sa.cuda(), sb.cuda(), torch.bfloat16, bias.cuda())
+    ref = ((a.cuda() @ w.cuda().t()) * sa.cuda() * (sb.cuda().t() if per_channel else 0.5)).to(torch.bfloat16)
+    ref = (ref.float() + bias.cuda().float()).to(torch.bfloat16)
+    assert torch.equal(out, ref)
+
+
 SPLIT_KERNELS = [3, 4, 5, 6, 7, 8, 9, 10, 12, 13]
 
 
