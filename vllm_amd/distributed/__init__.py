@@ -87,6 +87,30 @@ def bench_row_parallel(device, dist, M: int = 256, hidden: int = 8192, iters: in
             t = torch.tensor([(time.perf_counter() - t0) / iters], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             res[f"{name}_K{Ks}_{tag}"] = round(t.item() * 1e6, 2)
+        # the two legs above include the host's launch cost (Python + dispatcher, ~15 us per op);
+        # the GPU time alone, from a HIP graph of 20 quant + GEMM pairs
+        try:
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                gemm_only()
+            torch.cuda.current_stream(device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(iters):
+                    gemm_only()
+            graph.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            res[f"{name}_K{Ks}_quant_gemm_graph_us"] = round(e0.elapsed_time(e1) * 1e3 / (5 * iters), 2)
+            del graph
+        except Exception as e:   # capture is an extra, never fatal
+            res[f"{name}_K{Ks}_quant_gemm_graph_us"] = f"n/a ({type(e).__name__})"
     y = torch.randn((M, hidden), device=device, dtype=torch.bfloat16)
     for _ in range(3):
         dist.all_reduce(y)
