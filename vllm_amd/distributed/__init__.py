@@ -89,6 +89,8 @@ def bench_row_parallel(device, dist, M: int = 256, hidden: int = 8192, iters: in
             res[f"{name}_K{Ks}_{tag}"] = round(t.item() * 1e6, 2)
         # the two legs above include the host's launch cost (Python + dispatcher, ~15 us per op);
         # the GPU time alone, from a HIP graph of 20 quant + GEMM pairs
+        if world > 1:   # capture next to a live RCCL watchdog is not worth the risk: one rank only
+            continue
         try:
             side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream(device))
@@ -96,7 +98,7 @@ def bench_row_parallel(device, dist, M: int = 256, hidden: int = 8192, iters: in
                 gemm_only()
             torch.cuda.current_stream(device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 for _ in range(iters):
                     gemm_only()
             graph.replay()
