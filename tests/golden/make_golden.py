@@ -7,6 +7,12 @@ container (needs oracle/_ref/librefcpu.so built from /root/reference by oracle/M
 Sources of the expected outputs
   attn_ref_*.pt     the reference's OWN CPU kernels (csrc/cpu/attention.cpp via oracle/_ref):
                     paged_attention_v1 and _v2, bf16 / fp16 / fp32, block 16, with and without alibi
+  attnfp8_ref_*.pt  fp8-e4m3 KV (the headline workload): the cache is dequantised element by
+                    element to the query dtype, scalar_t(float(fp8) * scale) -- what
+                    quant_utils.cuh:338-345, 436-457 does inside the GPU kernel and what the
+                    reference's own test does with convert_fp8 (test_attention.py:306-322) -- and
+                    the reference's CPU kernels run on the dequantised 16-bit cache.  Stored:
+                    fp8 codes, k_scale != v_scale, and the reference's v1 / v2 outputs.
   cache_ref_*.pt    the reference's own CPU reshape_and_cache (csrc/cpu/cache.cpp via oracle/_ref)
   fp8_quant_*.pt    torch CPU restatement of the formulas in the reference's test helpers
                     (tests/kernels/quant_utils.py:22-97: ref_dynamic_per_token_quant,
@@ -66,6 +72,51 @@ def attention():
             if c["slopes"] is not None:
                 d["slopes"] = c["slopes"]
             save(f"attn_ref_{tag}_h{H}kv{KVH}.pt", d)
+
+
+def _dequant_cache(kc8, vc8, dtype, k_scale, v_scale):
+    """fp8 paged cache (x = 16) -> 16-bit paged cache (x = 8) holding scalar_t(float(fp8) * scale)."""
+    NB, KVH, DX, BS, X = kc8.shape
+    D = DX * X
+    k = (kc8.view(torch.float8_e4m3fn).float() * torch.tensor(k_scale, dtype=torch.float32)).to(dtype)
+    v = (vc8.view(torch.float8_e4m3fn).float() * torch.tensor(v_scale, dtype=torch.float32)).to(dtype)
+    k = k.permute(0, 1, 2, 4, 3).reshape(NB, KVH, D, BS)            # [NB, KVH, d, tok]
+    x = 16 // k.element_size()
+    k = k.reshape(NB, KVH, D // x, x, BS).permute(0, 1, 2, 4, 3).contiguous()
+    return k, v.contiguous()
+
+
+def attention_fp8kv():
+    assert O.load_ref(), "build oracle/_ref first (make -C oracle ref)"
+    one = torch.ones(1)
+    cases = (("bf16", torch.bfloat16, 16, 4, [1, 15, 16, 17, 300, 513, 1029], 0.037, 0.021, False),
+             ("fp16", torch.float16, 8, 1, [1, 64, 65, 257, 770], 0.05, 0.11, True),
+             ("bf16", torch.bfloat16, 16, 2, [5, 511, 512, 1100], 1.0, 0.5, False))
+    for tag, dtype, H, KVH, lens, ks, vs, alibi in cases:
+        # codes of U(-d^-.5, d^-.5) / scale: spread over the e4m3 range like a calibrated cache
+        c = make_attn_case(len(lens), H, KVH, 128, 16, dtype, "fp8", lens, seed=H + 3 * KVH,
+                           kv_scale=ks, alibi=alibi)
+        vc8 = make_attn_case(len(lens), H, KVH, 128, 16, dtype, "fp8", lens, seed=H + 3 * KVH,
+                             kv_scale=vs)["vc"]
+        kd, vd = _dequant_cache(c["kc"], vc8, dtype, ks, vs)
+        out1 = torch.empty_like(c["q"])
+        torch.ops.refcpu.paged_attention_v1(out1, c["q"], kd, vd, KVH, c["scale"], c["bt"], c["sl"],
+                                            16, c["max_len"], c["slopes"], "auto", one, one,
+                                            0, 0, 0, 64, 0)
+        P = (c["max_len"] + 511) // 512
+        S, _, D = c["q"].shape
+        es = torch.zeros((S, H, P)); ml = torch.zeros_like(es)
+        tmp = torch.zeros((S, H, P, D), dtype=dtype)
+        out2 = torch.empty_like(c["q"])
+        torch.ops.refcpu.paged_attention_v2(out2, es, ml, tmp, c["q"], kd, vd, KVH, c["scale"],
+                                            c["bt"], c["sl"], 16, c["max_len"], c["slopes"], "auto",
+                                            one, one, 0, 0, 0, 64, 0)
+        d = dict(q=c["q"], kc=c["kc"], vc=vc8, bt=c["bt"], sl=c["sl"], out_v1=out1, out_v2=out2,
+                 scale=torch.tensor(c["scale"]), num_kv_heads=torch.tensor(KVH),
+                 k_scale=torch.tensor(ks), v_scale=torch.tensor(vs))
+        if c["slopes"] is not None:
+            d["slopes"] = c["slopes"]
+        save(f"attnfp8_ref_{tag}_h{H}kv{KVH}.pt", d)
 
 
 def cache():
@@ -212,4 +263,4 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        attention(); cache(); fp8_quant(); scaled_mm(); fp8_codec(); fused_quant(); slot_mapping()
+        attention(); attention_fp8kv(); cache(); fp8_quant(); scaled_mm(); fp8_codec(); fused_quant(); slot_mapping()

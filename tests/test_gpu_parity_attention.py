@@ -197,3 +197,46 @@ def test_unsupported_raises(ops):
         ops.paged_attention_v1(torch.empty_like(q), q, kc, vc, 8, 1.0, bt, sl, 16, 1, None, "auto", one, one)
     with pytest.raises(RuntimeError, match="Unsupported data type of kv cache"):
         ops.paged_attention_v1(torch.empty_like(q), q, kc, vc, 8, 1.0, bt, sl, 16, 1, None, "fp8_e5m2", one, one)
+
+
+import glob as _glob
+import os as _os
+
+_GOLD = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(_glob.glob(_os.path.join(_GOLD, "attnfp8_ref_*.pt"))),
+                         ids=lambda p: _os.path.basename(p))
+@pytest.mark.parametrize("version", ["v1", "v2", "rocm"])
+def test_fp8kv_reference_executed_golden(ops, path, version):
+    """HIP fp8-KV decode (k_scale != v_scale) against outputs the reference's own CPU kernels
+    produced on the per-element dequantised cache (tests/golden/make_golden.py attention_fp8kv;
+    the route of the reference's test, test_attention.py:306-322).  Tolerance: the reference's for
+    fp8 KV (:345-348) atol 1e-2 / rtol 1e-5, and our tighter 2e-3 bound."""
+    d = torch.load(path, weights_only=True)
+    q, kc, vc, bt, sl = (d[k].cuda() for k in ("q", "kc", "vc", "bt", "sl"))
+    KVH, scale = int(d["num_kv_heads"]), float(d["scale"])
+    slopes = d["slopes"].cuda() if "slopes" in d else None
+    ks = d["k_scale"].reshape(1).float().cuda()
+    vs = d["v_scale"].reshape(1).float().cuda()
+    max_len = int(d["sl"].max())
+    S, H, D = q.shape
+    out = torch.full_like(q, float("nan"))
+    if version == "v1":
+        ops.paged_attention_v1(out, q, kc, vc, KVH, scale, bt, sl, 16, max_len, slopes, "fp8", ks, vs)
+        want = d["out_v1"]
+    else:
+        PS = 512 if version == "v2" else 256
+        P = (max_len + PS - 1) // PS
+        es = torch.zeros((S, H, P), device="cuda"); ml = torch.zeros_like(es)
+        tmp = torch.zeros((S, H, P, D), dtype=q.dtype, device="cuda")
+        if version == "v2":
+            ops.paged_attention_v2(out, es, ml, tmp, q, kc, vc, KVH, scale, bt, sl, 16, max_len,
+                                   slopes, "fp8", ks, vs)
+        else:
+            ops.paged_attention_rocm(out, es, ml, tmp, q, kc, vc, KVH, scale, bt, sl, None, 16,
+                                     max_len, slopes, "fp8", ks, vs)
+        want = d["out_v2"]
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu().float(), want.float(), atol=1e-2, rtol=1e-5)
+    assert (out.cpu().float() - want.float()).abs().max().item() < 2e-3
