@@ -6,9 +6,10 @@
  * paths relative to the ROCm/vllm tree).  Conventions, identical to the
  * reference's op contract:
  *   - all pointers are DEVICE pointers owned by the caller (including the
- *     temporaries tmp_out/exp_sums/max_logits and the pre-zeroed dynamic
- *     scale); nothing is allocated, freed or synchronised inside a call, so
- *     every call is HIP-graph capturable;
+ *     temporaries tmp_out/exp_sums/max_logits, the pre-zeroed dynamic scale
+ *     and the optional split-K workspace of scaled_mm); nothing is allocated,
+ *     freed or synchronised inside a call, so every call is HIP-graph
+ *     capturable;
  *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
  *     default stream) of the CURRENT device;
  *   - strides are in ELEMENTS of the tensor they describe;
@@ -189,6 +190,18 @@ int vllm_amd_scaled_mm(void* out, const void* a, const void* b,
                        int64_t ldb, int64_t ldc, int a_scale_numel,
                        int b_scale_numel, int out_dtype, void* stream);
 
+/* No counterpart in the reference (its GEMM libraries own their workspaces): registers
+ * (ws != NULL) or removes (ws == NULL) the CURRENT device's split-K workspace of
+ * vllm_amd_scaled_mm -- `bytes` of caller-owned device memory, 256-byte aligned, valid until
+ * replaced or removed; at least 64 KiB + 1 KiB, useful from 64 KiB + 4 x 2 MiB.  Its ticket
+ * counters are zeroed on `stream` (asynchronously: order the first GEMM behind it).  Without a
+ * workspace every GEMM runs unsplit.  With one, the few shapes the heuristic splits (M <= 64,
+ * K >= 12288, <= 128 tiles of 64 x 32) reduce their K slices in-kernel through it: the
+ * workspace is cut into 4 slots, a slot belongs to the first stream that asks for it, launches
+ * of one stream share their slot (they are ordered), a fifth stream, a launch under stream
+ * capture and a launch that needs more than a slot run unsplit. */
+int vllm_amd_scaled_mm_set_workspace(void* ws, int64_t bytes, void* stream);
+
 /* Replaces torch.ops._rocm_C.wvSplitKQ
  *   schema csrc/rocm/torch_bindings.cpp:34-37, csrc/rocm/skinny_gemms.cu:1649-1714,
  *   python vllm/_custom_ops.py:1501-1508.
@@ -359,7 +372,8 @@ int vllm_amd_unified_attention(
 /*   "cache_runs": 0 = reshape_and_cache always per token (no run detection)    */
 /*   "mm_splitk":  K slices per output tile of the direct-to-LDS kernels        */
 /*                 (0 = heuristic, 1 = never split, n = n slices; reduced       */
-/*                 inside the kernel through a per-device fp32 workspace)       */
+/*                 inside the kernel through the registered workspace,          */
+/*                 vllm_amd_scaled_mm_set_workspace; unsplit without one)       */
 /* ------------------------------------------------------------------------- */
 int vllm_amd_set_tuning(const char* key, int value);
 

@@ -223,3 +223,51 @@ def test_scaled_mm_split_k_two_streams(ops, force_kernel):
     for o in res:
         torch.testing.assert_close(o.float(), ref.float(), rtol=1.6e-2, atol=5e-3)
         assert torch.equal(o, res[0])
+
+
+def test_scaled_mm_split_k_more_streams_than_slots(ops, force_kernel):
+    """The registered workspace has 4 stream slots: launches from 6 streams at once stay correct
+    (the fifth and sixth stream run unsplit) and the slot owners agree to the bit."""
+    M, N, K = 64, 2048, 4096
+    ar, wr, sa, sb, _ = make(M, N, K, 12, True, True, torch.bfloat16, False)
+    ar, wr, sa, sb = ar.cuda(), wr.cuda(), sa.cuda(), sb.cuda()
+    force_kernel(9, 1)
+    ref = ops.cutlass_scaled_mm(ar, wr.t(), sa, sb, torch.bfloat16)
+    force_kernel(9, 4)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    res = []
+    for _ in range(6):
+        for st in streams:
+            with torch.cuda.stream(st):
+                res.append(ops.cutlass_scaled_mm(ar, wr.t(), sa, sb, torch.bfloat16))
+    torch.cuda.synchronize()
+    for o in res:
+        torch.testing.assert_close(o.float(), ref.float(), rtol=1.6e-2, atol=5e-3)
+
+
+def test_scaled_mm_split_k_graph_capture(ops, force_kernel):
+    """A launch under stream capture never takes a workspace slot (it runs unsplit), so a
+    replayed graph cannot meet eager split launches in the workspace; nothing is allocated or
+    synchronised inside the captured call."""
+    M, N, K = 48, 1024, 14336
+    ar, wr, sa, sb, _ = make(M, N, K, 13, True, True, torch.bfloat16, False)
+    ar, wr, sa, sb = ar.cuda(), wr.cuda(), sa.cuda(), sb.cuda()
+    force_kernel(9, 1)
+    ref = ops.cutlass_scaled_mm(ar, wr.t(), sa, sb, torch.bfloat16)     # also registers the workspace
+    force_kernel(9, 2)
+    eager = ops.cutlass_scaled_mm(ar, wr.t(), sa, sb, torch.bfloat16)   # split
+    torch.cuda.synchronize()
+    out = torch.empty_like(ref)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            torch.ops._C.cutlass_scaled_mm(out, ar, wr.t(), sa, sb, None)
+        for _ in range(3):
+            g.replay()
+            again = ops.cutlass_scaled_mm(ar, wr.t(), sa, sb, torch.bfloat16)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)          # captured = unsplit
+    assert torch.equal(again, eager)
+    torch.testing.assert_close(eager.float(), ref.float(), rtol=1.6e-2, atol=5e-3)

@@ -271,3 +271,42 @@ def test_unified_rejects_what_it_does_not_cover():
         unified_attention(c["q"].cuda(), c["k"].cuda(), c["v"].cuda(), out, c["cu_seqlens_q"].cuda(),
                           4, c["seqused_k"].cuda(), 40, 0.1, True, (-1, -1), c["block_table"].cuda(),
                           0, None, None, None)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_unified_mixed_batch_with_caller_segments_c_abi(oracle, fp8):
+    """C-ABI level (include/vllm_amd.h): a mixed batch of >= 16 sequences with query lengths
+    1..4 whose caller passes num_segments = 16 scratch.  The decode tokens are written by the
+    decode kernel; the segment merge of the tile path must leave them alone (their segm_* rows
+    are never written: poisoned with NaN here)."""
+    from vllm_amd import _lib
+    from vllm_amd._lib import check, lib
+    from vllm_amd._torch_ops import _ptr, _stream
+    dtype, H, KVH, D, BS = torch.bfloat16, 8, 2, 128, 16
+    seq_lens = [(1 + (i % 4) if i % 3 else 1, 40 + 97 * i) for i in range(20)]
+    c = make_unified_case(seq_lens, H, KVH, D, BS, dtype, fp8=fp8, seed=5, kv_scale=0.05 if fp8 else 1.0)
+    sm = D ** -0.5
+    kd = c["scale"] if fp8 else None
+    ref = torch.zeros(c["q"].shape, dtype=dtype)
+    oracle.unified_attention(c["q"], c["k"], c["v"], ref, c["cu_seqlens_q"], c["max_seqlen_q"],
+                             c["seqused_k"], c["max_seqlen_k"], sm, True, (-1, -1), c["block_table"],
+                             0.0, None, kd, kd, None, None)
+    q, k, v = c["q"].cuda(), c["k"].cuda(), c["v"].cuda()
+    cu, sk, bt = c["cu_seqlens_q"].cuda(), c["seqused_k"].cuda(), c["block_table"].cuda()
+    kdd = None if kd is None else kd.cuda()
+    out = torch.zeros_like(q)
+    nseg = 16
+    T = q.shape[0]
+    segm_out = torch.full((T, H, nseg, D), float("nan"), dtype=torch.float32, device="cuda")
+    segm_max = torch.full((T, H, nseg), float("nan"), dtype=torch.float32, device="cuda")
+    segm_sum = torch.full((T, H, nseg), float("nan"), dtype=torch.float32, device="cuda")
+    check(lib.vllm_amd_unified_attention(
+        _ptr(out), _ptr(q), _ptr(k), _ptr(v), _ptr(cu), _ptr(sk), _ptr(bt), _ptr(kdd), _ptr(kdd),
+        None, None, len(seq_lens), H, KVH, D, BS, c["max_seqlen_q"], bt.stride(0), q.stride(0),
+        q.stride(1), out.stride(0), out.stride(1), k.stride(0), k.stride(1), k.stride(2),
+        v.stride(0), v.stride(1), v.stride(2), float(sm), 0, 0.0, T, c["max_seqlen_k"],
+        _ptr(segm_out), _ptr(segm_max), _ptr(segm_sum), nseg, _lib.BF16,
+        _lib.KV_FP8_E4M3 if fp8 else _lib.KV_AUTO, _stream(q)))
+    torch.cuda.synchronize()
+    assert not out.isnan().any()
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=ATOL, rtol=RTOL)

@@ -699,6 +699,9 @@ __global__ __launch_bounds__(64) void unified_reduce_kernel(const PrefillParams 
   }
   const int seq_len = p.b_seq_len[seq];
   const int qlen = p.b_start_loc[seq + 1] - p.b_start_loc[seq];
+  // mixed launch: the decode kernel has already written this token's output and the tile kernel
+  // skipped its sequence, so its segm_* rows hold nothing
+  if (p.skip_decode && qlen == 1) return;
   const int kv_end = min(seq_len - qlen + min(rows_per_block, qlen), seq_len);
   const int ntiles = (kv_end + PF_BN - 1) / PF_BN;
   const int tps = (ntiles + p.num_segments - 1) / p.num_segments;

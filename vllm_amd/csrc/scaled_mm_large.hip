@@ -416,49 +416,44 @@ struct GldsArgs {
   int splits;
 };
 
-// Split-K workspace, one per device: a ring of fp32 partials and a ring of ticket counters.
-// Every launch takes the next slice of both rings, so launches that overlap on different
-// streams work on different memory unless more than a ring's worth of them is in flight at
-// once (documented in DESIGN.md; "mm_splitk" = 1 turns splitting off).  Allocated on the
-// first split launch on the device -- never during stream capture: such a call runs
-// unsplit -- and kept until the process ends.  Counters reset themselves (kernel above).
-constexpr size_t SPLIT_WS_BYTES = (size_t)64 << 20;
-constexpr int SPLIT_WS_TILES = 16384;
-struct SplitWs { float* ws; unsigned* ctr; size_t cursor; int ctr_cursor; };
+// Split-K workspace: CALLER-OWNED device memory registered per device with
+// vllm_amd_scaled_mm_set_workspace() (below) -- nothing is allocated in an op call; without a
+// registered workspace every launch runs unsplit.  Layout: SPLIT_SLOTS ticket-counter areas of
+// SPLIT_CTR_TILES words, then SPLIT_SLOTS equal areas of fp32 partials.  A slot belongs to ONE
+// stream (assigned at that stream's first split launch, kept until the workspace is replaced):
+// launches of one stream are ordered, so they may share a slot; streams never share one.  A
+// stream that finds no free slot, a launch under stream capture (the graph could replay on any
+// stream, beside eager launches), and a launch that needs more than a slot all run unsplit.
+// Counters reset themselves (kernel above) and are zeroed when the workspace is registered.
+constexpr int SPLIT_SLOTS = 4;
+constexpr int SPLIT_CTR_TILES = 4096;
+constexpr size_t SPLIT_CTR_BYTES = (size_t)SPLIT_SLOTS * SPLIT_CTR_TILES * sizeof(unsigned);
+struct SplitWs { char* base; size_t slot_bytes; hipStream_t streams[SPLIT_SLOTS]; int nstreams; };
 static SplitWs g_split_ws[64];
 static std::mutex g_split_mu;
 
 static bool split_workspace(hipStream_t st, size_t bytes, int tiles, float** ws, unsigned** ctr) {
   int dev = 0;
-  if (bytes > SPLIT_WS_BYTES || tiles > SPLIT_WS_TILES) return false;
+  if (tiles > SPLIT_CTR_TILES) return false;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
   std::lock_guard<std::mutex> lk(g_split_mu);
   SplitWs& w = g_split_ws[dev];
-  if (!w.ws) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-      (void)hipGetLastError();
-      return false;
-    }
-    void* p = nullptr;
-    if (hipMalloc(&p, SPLIT_WS_BYTES + SPLIT_WS_TILES * sizeof(unsigned)) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-    if (hipMemset((char*)p + SPLIT_WS_BYTES, 0, SPLIT_WS_TILES * sizeof(unsigned)) != hipSuccess) {
-      (void)hipGetLastError();
-      (void)hipFree(p);
-      return false;
-    }
-    w = {(float*)p, (unsigned*)((char*)p + SPLIT_WS_BYTES), 0, 0};
+  if (!w.base || bytes > w.slot_bytes) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return false;
   }
-  bytes = (bytes + 255) & ~(size_t)255;
-  if (w.cursor + bytes > SPLIT_WS_BYTES) w.cursor = 0;
-  if (w.ctr_cursor + tiles > SPLIT_WS_TILES) w.ctr_cursor = 0;
-  *ws = (float*)((char*)w.ws + w.cursor);
-  *ctr = w.ctr + w.ctr_cursor;
-  w.cursor += bytes;
-  w.ctr_cursor += tiles;
+  int slot = -1;
+  for (int i = 0; i < w.nstreams; ++i)
+    if (w.streams[i] == st) slot = i;
+  if (slot < 0) {
+    if (w.nstreams == SPLIT_SLOTS) return false;
+    slot = w.nstreams++;
+    w.streams[slot] = st;
+  }
+  *ctr = (unsigned*)w.base + (size_t)slot * SPLIT_CTR_TILES;
+  *ws = (float*)(w.base + SPLIT_CTR_BYTES + (size_t)slot * w.slot_bytes);
   return true;
 }
 
@@ -529,3 +524,35 @@ void launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
 }
 
 }  // namespace va
+
+// Registers (ws != NULL) or removes (ws == NULL) the calling device's split-K workspace of
+// vllm_amd_scaled_mm: `bytes` of caller-owned device memory, 256-byte aligned, that must stay
+// valid until it is replaced or removed.  The ticket counters at its start are zeroed on `stream`
+// (asynchronously: order the first scaled_mm call behind it).  Replacing a workspace while
+// split launches are in flight is the caller's race.
+extern "C" int vllm_amd_scaled_mm_set_workspace(void* ws, int64_t bytes, void* stream) {
+  using namespace va;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    set_error("scaled_mm_set_workspace: no current device");
+    return VLLM_AMD_EHIP;
+  }
+  if (ws == nullptr) {
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    g_split_ws[dev] = SplitWs{};
+    return VLLM_AMD_OK;
+  }
+  VA_REQUIRE((((uintptr_t)ws) & 255) == 0, VLLM_AMD_EINVAL,
+             "scaled_mm_set_workspace: the workspace must be 256-byte aligned");
+  VA_REQUIRE(bytes >= (int64_t)(SPLIT_CTR_BYTES + SPLIT_SLOTS * 256), VLLM_AMD_EINVAL,
+             "scaled_mm_set_workspace: workspace of %lld bytes is too small (minimum %lld)",
+             (long long)bytes, (long long)(SPLIT_CTR_BYTES + SPLIT_SLOTS * 256));
+  hipError_t e = hipMemsetAsync(ws, 0, SPLIT_CTR_BYTES, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "scaled_mm_set_workspace");
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  SplitWs w{};
+  w.base = (char*)ws;
+  w.slot_bytes = (((size_t)bytes - SPLIT_CTR_BYTES) / SPLIT_SLOTS) & ~(size_t)255;
+  g_split_ws[dev] = w;
+  return VLLM_AMD_OK;
+}
