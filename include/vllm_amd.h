@@ -202,6 +202,24 @@ int vllm_amd_scaled_mm(void* out, const void* a, const void* b,
  * capture and a launch that needs more than a slot run unsplit. */
 int vllm_amd_scaled_mm_set_workspace(void* ws, int64_t bytes, void* stream);
 
+/* No counterpart in the reference.  The ONE entry point for callers that cannot allocate or
+ * register device memory (code under HIP-graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc): vllm_amd_scaled_mm with its split-K partials and tickets in a file-scope
+ * static __device__ array of the library (8 MiB + 16 KiB per GPU the library runs on, held until
+ * the process ends) instead of a registered workspace.  Same arguments and results as
+ * vllm_amd_scaled_mm, plus `splits`: K slices per output tile (0 = the heuristic of
+ * vllm_amd_scaled_mm, 1 = never split, n = n slices, at most the number of K blocks).  A split
+ * that needs more than the array holds (tiles x slices x tile bytes > 8 MiB, or > 4096 tiles)
+ * returns VLLM_AMD_EUNSUPPORTED with a message; nothing is allocated, freed or synchronised (one
+ * hipMemsetAsync on `stream` clears the launch's tickets).  Every call on a GPU shares that
+ * GPU's array: calls that overlap on one GPU (different streams, or a replaying graph beside
+ * eager calls) race -- serialise them. */
+int vllm_amd_scaled_mm_static(void* out, const void* a, const void* b,
+                              const float* a_scales, const float* b_scales,
+                              const void* bias, int M, int N, int K, int64_t lda,
+                              int64_t ldb, int64_t ldc, int a_scale_numel,
+                              int b_scale_numel, int out_dtype, int splits, void* stream);
+
 /* Replaces torch.ops._rocm_C.wvSplitKQ
  *   schema csrc/rocm/torch_bindings.cpp:34-37, csrc/rocm/skinny_gemms.cu:1649-1714,
  *   python vllm/_custom_ops.py:1501-1508.

@@ -267,10 +267,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void scaled_mm_skinny_kernel(
 }
 
 // scaled_mm_large.hip
-void launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
-                            const float* a_scales, const float* b_scales, const void* bias, int M,
-                            int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int asn, int bsn,
-                            int out_dtype, bool vec, int splits, hipStream_t st);
+int launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
+                           const float* a_scales, const float* b_scales, const void* bias, int M,
+                           int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int asn, int bsn,
+                           int out_dtype, bool vec, int splits, int ws_mode, hipStream_t st);
 bool scaled_mm_large_fits(int M, int N, int K, int64_t lda, int64_t ldb);
 int g_mm_kernel = 0;   // tuning: 0 auto, 1 = register-staged 128x128, 2..10, 12, 13 = glds tile shapes
 int g_mm_splitk = 0;   // tuning: 0 auto, n >= 1 = n K slices (1 = never split)
@@ -282,7 +282,8 @@ using namespace va;
 static int launch_scaled_mm(void* out, const void* a, const void* b, const float* a_scales,
                             const float* b_scales, const void* bias, int M, int N, int K,
                             int64_t lda, int64_t ldb, int64_t ldc, int a_scale_numel,
-                            int b_scale_numel, int out_dtype, hipStream_t st, const char* op) {
+                            int b_scale_numel, int out_dtype, hipStream_t st, const char* op,
+                            int ws_mode = 0, int req_splits = 0) {
   VA_REQUIRE(M >= 0 && N >= 0 && K >= 0, VLLM_AMD_EINVAL, "%s: negative dimension", op);
   if (M == 0 || N == 0) return VLLM_AMD_OK;
   VA_REQUIRE(out && a && b && a_scales && b_scales, VLLM_AMD_EINVAL, "%s: null pointer", op);
@@ -324,7 +325,8 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
   const bool vec = (ldc % 4 == 0) && ((((uintptr_t)out) & 7) == 0);
   if (glds_ok) {
     int sel = g_mm_kernel;
-    int splits = g_mm_splitk > 0 ? g_mm_splitk : 1;
+    const int want_splits = req_splits > 0 ? req_splits : g_mm_splitk;   // 0 = heuristic
+    int splits = want_splits > 0 ? want_splits : 1;
     if (sel == 0 || sel == 11 || sel > 13) {
       // Largest tile that still yields ~3/4 of a full wave of workgroups (256 CUs); rows of
       // a tile beyond M are wasted MFMA work, so BM <= 2 M.  With >= 1.5 waves of tiles the
@@ -345,7 +347,7 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
           // device-scope round trips (~2.5 us), so it pays only here: 14336x4096, M 16..64:
           // 17.2 -> 15.2 us; everywhere else on the grid splitting loses
           // (profiles/r01_gemm_sweep_splitk.csv; at K = 8192 it is 11.5 vs 11.1 us).
-          if (i == 4 && nt <= 128 && K >= 12288 && g_mm_splitk == 0) splits = 2;
+          if (i == 4 && nt <= 128 && K >= 12288 && want_splits == 0) splits = 2;
           break;
         }
       }
@@ -365,18 +367,20 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
           const int n2 = c * 256, n1 = N - n2;
           const int64_t osz = 2;   // bf16 / f16
           launch_scaled_mm_large(2, out, a, b, a_scales, b_scales, bias, M, n1, K, lda, ldb, ldc,
-                                 a_scale_numel, b_scale_numel == 1 ? 1 : n1, out_dtype, vec16, 1, st);
+                                 a_scale_numel, b_scale_numel == 1 ? 1 : n1, out_dtype, vec16, 1, 0, st);
           launch_scaled_mm_large(3, (char*)out + n1 * osz, a, (const char*)b + (int64_t)n1 * ldb,
                                  a_scales, b_scale_numel == 1 ? b_scales : b_scales + n1,
                                  bias ? (const char*)bias + n1 * osz : nullptr, M, n2, K, lda, ldb,
                                  ldc, a_scale_numel, b_scale_numel == 1 ? 1 : n2, out_dtype, vec16, 1,
-                                 st);
+                                 0, st);
           VA_LAUNCH_CHECK(op);
           return VLLM_AMD_OK;
         }
       }
-      launch_scaled_mm_large(sel, out, a, b, a_scales, b_scales, bias, M, N, K,
-                             lda, ldb, ldc, a_scale_numel, b_scale_numel, out_dtype, vec16, splits, st);
+      const int rc = launch_scaled_mm_large(sel, out, a, b, a_scales, b_scales, bias, M, N, K, lda,
+                                            ldb, ldc, a_scale_numel, b_scale_numel, out_dtype, vec16,
+                                            splits, ws_mode, st);
+      if (rc != VLLM_AMD_OK) return rc;
       VA_LAUNCH_CHECK(op);
       return VLLM_AMD_OK;
     }
@@ -399,6 +403,20 @@ extern "C" int vllm_amd_scaled_mm(void* out, const void* a, const void* b, const
   return launch_scaled_mm(out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc,
                           a_scale_numel, b_scale_numel, out_dtype, (hipStream_t)stream,
                           "scaled_mm");
+}
+
+// The variant of vllm_amd_scaled_mm for callers that cannot allocate or register memory: split-K
+// partials and tickets live in the library's static device array (scaled_mm_large.hip).
+extern "C" int vllm_amd_scaled_mm_static(void* out, const void* a, const void* b,
+                                         const float* a_scales, const float* b_scales,
+                                         const void* bias, int M, int N, int K, int64_t lda,
+                                         int64_t ldb, int64_t ldc, int a_scale_numel,
+                                         int b_scale_numel, int out_dtype, int splits,
+                                         void* stream) {
+  VA_REQUIRE(splits >= 0, VLLM_AMD_EINVAL, "scaled_mm_static: negative number of K slices");
+  return launch_scaled_mm(out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc,
+                          a_scale_numel, b_scale_numel, out_dtype, (hipStream_t)stream,
+                          "scaled_mm_static", 1, splits);
 }
 
 // out_c[N_in, M_in] = (in_b[N_in,K] . in_a[M_in,K]^T) * scale_a * scale_b

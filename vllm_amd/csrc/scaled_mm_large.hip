@@ -414,6 +414,7 @@ struct GldsArgs {
   void* out; const void* a; const void* b; const float* a_scales; const float* b_scales;
   const void* bias; int M, N, K; int64_t lda, ldb, ldc; int asn, bsn; bool vec; hipStream_t st;
   int splits;
+  int ws_mode;   // 0 = registered workspace (or unsplit), 1 = the static scratch below (or an error)
 };
 
 // Split-K workspace: CALLER-OWNED device memory registered per device with
@@ -457,6 +458,43 @@ static bool split_workspace(hipStream_t st, size_t bytes, int tiles, float** ws,
   return true;
 }
 
+// Scratch of vllm_amd_scaled_mm_static (the entry point for callers that cannot allocate or
+// register anything): one array per GPU the library runs on, held until the process ends.  In
+// host code the array's NAME is only a stand-in: the device address comes from
+// hipGetSymbolAddress, once per device, and that pointer is what kernels and memsets get.
+constexpr size_t STATIC_PART_BYTES = (size_t)8 << 20;
+constexpr int STATIC_CTR_TILES = 4096;
+static __device__ __align__(256) unsigned char g_mm_scratch[STATIC_PART_BYTES + STATIC_CTR_TILES * sizeof(unsigned)];
+static unsigned char* g_mm_scratch_ptr[64];
+
+static int static_workspace(hipStream_t st, size_t bytes, int tiles, float** ws, unsigned** ctr) {
+  VA_REQUIRE(bytes <= STATIC_PART_BYTES && tiles <= STATIC_CTR_TILES, VLLM_AMD_EUNSUPPORTED,
+             "scaled_mm_static: this split needs %zu bytes of partials for %d tiles; the static "
+             "scratch holds %zu bytes and %d tiles (use fewer K slices, or vllm_amd_scaled_mm with "
+             "a registered workspace)", bytes, tiles, STATIC_PART_BYTES, STATIC_CTR_TILES);
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_fail(e, "scaled_mm_static");
+  VA_REQUIRE(dev >= 0 && dev < 64, VLLM_AMD_EUNSUPPORTED, "scaled_mm_static: device %d", dev);
+  unsigned char* base;
+  {
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    if (!g_mm_scratch_ptr[dev]) {
+      void* p = nullptr;
+      e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_mm_scratch));
+      if (e != hipSuccess || !p) return hip_fail(e, "scaled_mm_static: hipGetSymbolAddress");
+      g_mm_scratch_ptr[dev] = (unsigned char*)p;
+    }
+    base = g_mm_scratch_ptr[dev];
+  }
+  *ws = (float*)base;
+  *ctr = (unsigned*)(base + STATIC_PART_BYTES);
+  // the array keeps the last call's contents: the tickets of this launch start at zero
+  e = hipMemsetAsync(*ctr, 0, (size_t)tiles * sizeof(unsigned), st);
+  if (e != hipSuccess) return hip_fail(e, "scaled_mm_static: hipMemsetAsync");
+  return VLLM_AMD_OK;
+}
+
 #define GLDS_LAUNCH(VEC, SPLIT, GRID, WS, CTR, S)                                                  \
   hipLaunchKernelGGL((scaled_mm_glds_kernel<out_t, BM, BN, WM, WN, NST, KB, VEC, SPLIT>),          \
                      dim3(GRID), dim3(64 * WM * WN), 0, g.st, (out_t*)g.out, (const uint8_t*)g.a,  \
@@ -464,7 +502,7 @@ static bool split_workspace(hipStream_t st, size_t bytes, int tiles, float** ws,
                      g.K, g.lda, g.ldb, g.ldc, g.asn, g.bsn, WS, CTR, S)
 
 template <typename out_t, int BM, int BN, int WM, int WN, int NST, int KB, bool CAN_SPLIT>
-static void launch_glds_t(const GldsArgs& g) {
+static int launch_glds_t(const GldsArgs& g) {
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   if constexpr (CAN_SPLIT) {
     int S = g.splits;
@@ -472,31 +510,40 @@ static void launch_glds_t(const GldsArgs& g) {
     if (S > ng) S = ng;
     float* ws = nullptr;
     unsigned* ctr = nullptr;
-    if (S > 1 && g.vec &&
-        split_workspace(g.st, (size_t)tiles * S * BM * BN * sizeof(float), tiles, &ws, &ctr)) {
-      GLDS_LAUNCH(true, true, tiles * S, ws, ctr, S);
-      return;
+    if (S > 1 && g.vec) {
+      const size_t need = (size_t)tiles * S * BM * BN * sizeof(float);
+      if (g.ws_mode == 1) {
+        const int rc = static_workspace(g.st, need, tiles, &ws, &ctr);
+        if (rc != VLLM_AMD_OK) return rc;
+        GLDS_LAUNCH(true, true, tiles * S, ws, ctr, S);
+        return VLLM_AMD_OK;
+      }
+      if (split_workspace(g.st, need, tiles, &ws, &ctr)) {
+        GLDS_LAUNCH(true, true, tiles * S, ws, ctr, S);
+        return VLLM_AMD_OK;
+      }
     }
   }
   if (g.vec) GLDS_LAUNCH(true, false, tiles, nullptr, nullptr, 1);
   else GLDS_LAUNCH(false, false, tiles, nullptr, nullptr, 1);
+  return VLLM_AMD_OK;
 }
 #undef GLDS_LAUNCH
 
 template <typename out_t>
-static void launch_glds_shape(int shape, const GldsArgs& g) {
+static int launch_glds_shape(int shape, const GldsArgs& g) {
   switch (shape) {
-    case 2: launch_glds_t<out_t, 256, 256, 2, 4, 2, 1, false>(g); break;
-    case 3: launch_glds_t<out_t, 128, 128, 2, 4, 2, 1, true>(g); break;
-    case 4: launch_glds_t<out_t, 128, 128, 2, 4, 2, 2, true>(g); break;
-    case 5: launch_glds_t<out_t, 128, 64, 4, 2, 3, 1, true>(g); break;
-    case 6: launch_glds_t<out_t, 128, 64, 4, 2, 3, 2, true>(g); break;
-    case 7: launch_glds_t<out_t, 64, 64, 2, 2, 4, 1, true>(g); break;
-    case 8: launch_glds_t<out_t, 64, 64, 2, 2, 2, 4, true>(g); break;
-    case 9: launch_glds_t<out_t, 64, 32, 2, 2, 4, 1, true>(g); break;
-    case 10: launch_glds_t<out_t, 64, 32, 2, 2, 3, 4, true>(g); break;
-    case 12: launch_glds_t<out_t, 32, 128, 1, 4, 4, 1, true>(g); break;
-    default: launch_glds_t<out_t, 32, 128, 1, 4, 3, 2, true>(g); break;   // 13
+    case 2: return launch_glds_t<out_t, 256, 256, 2, 4, 2, 1, false>(g);
+    case 3: return launch_glds_t<out_t, 128, 128, 2, 4, 2, 1, true>(g);
+    case 4: return launch_glds_t<out_t, 128, 128, 2, 4, 2, 2, true>(g);
+    case 5: return launch_glds_t<out_t, 128, 64, 4, 2, 3, 1, true>(g);
+    case 6: return launch_glds_t<out_t, 128, 64, 4, 2, 3, 2, true>(g);
+    case 7: return launch_glds_t<out_t, 64, 64, 2, 2, 4, 1, true>(g);
+    case 8: return launch_glds_t<out_t, 64, 64, 2, 2, 2, 4, true>(g);
+    case 9: return launch_glds_t<out_t, 64, 32, 2, 2, 4, 1, true>(g);
+    case 10: return launch_glds_t<out_t, 64, 32, 2, 2, 3, 4, true>(g);
+    case 12: return launch_glds_t<out_t, 32, 128, 1, 4, 4, 1, true>(g);
+    default: return launch_glds_t<out_t, 32, 128, 1, 4, 3, 2, true>(g);   // 13
   }
 }
 
@@ -508,19 +555,19 @@ bool scaled_mm_large_fits(int M, int N, int K, int64_t lda, int64_t ldb) {
 
 // Caller guarantees K % 128 == 0, 16-byte aligned operands and scaled_mm_large_fits();
 // vec = 16-byte aligned output rows (ldc % 8 == 0, N % 8 == 0, out 16-byte aligned).
-void launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
-                            const float* a_scales, const float* b_scales, const void* bias, int M,
-                            int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int asn, int bsn,
-                            int out_dtype, bool vec, int splits, hipStream_t st) {
+int launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
+                           const float* a_scales, const float* b_scales, const void* bias, int M,
+                           int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int asn, int bsn,
+                           int out_dtype, bool vec, int splits, int ws_mode, hipStream_t st) {
   // shape = a GldsTile::id of the table in scaled_mm.hip.  Shapes that consume KB blocks per
   // barrier need K % (128 KB) == 0; otherwise the same tile with KB = 1.
   static const int kb_of[14] = {1, 1, 1, 1, 2, 1, 2, 1, 4, 1, 4, 1, 1, 2};
   if (shape < 2 || shape > 13 || shape == 11) shape = 3;
   if (K % (LBK * kb_of[shape]) != 0) shape -= 1;
   const GldsArgs g{out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc, asn, bsn, vec, st,
-                   splits};
-  if (out_dtype == VLLM_AMD_BF16) launch_glds_shape<bf16_t>(shape, g);
-  else launch_glds_shape<f16_t>(shape, g);
+                   splits, ws_mode};
+  if (out_dtype == VLLM_AMD_BF16) return launch_glds_shape<bf16_t>(shape, g);
+  return launch_glds_shape<f16_t>(shape, g);
 }
 
 }  // namespace va
