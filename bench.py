@@ -10,9 +10,16 @@ batch 64, ctx 4096, 32 q / 8 kv heads, head 128, block 16, bf16 query/output.
 Inputs are resident in HBM before the timed region.  `value` = algorithmic bytes
 (K and V once + q/out + block tables + seq_lens) / time.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): attention shards by
-KV head with no collective, so every rank runs the same per-GPU
-shape on its own shard ("weak" scaling); value = bytes of all ranks / max time.
+N > 1: one rank per GPU, either launched by torch.distributed.run (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the env) or, when WORLD_SIZE is not set, by this script itself:
+`python bench.py --gpus N` spawns its N ranks before it touches a GPU and exits non-zero if
+any rank fails or the RCCL world is not N.  Attention shards by KV head with no collective
+(SURVEY.md 8e): the headline keeps the per-GPU configs[1] shape on every rank ("weak" scaling);
+value = bytes of all ranks / max time.  `extra` then carries, timed over all ranks (max):
+  configs4_strong   configs[4] (8 x 128k, 64q/8kv, fp8) with heads / N per rank: strong scaling
+  configs3_per_gpu  configs[3] per-GPU attention shape (256 x 32k, 8q/1kv) on every rank
+  row_parallel_tp   configs[3] row-parallel fp8 GEMMs (K 1024 / 3584 -> 8192, M 256) + one 4 MiB
+                    RCCL all-reduce (us, bus GB/s)
 
 The JSON line also carries
   roofline      dominant kernel vs the 8 TB/s HBM3E peak, HIP-event timed
@@ -146,6 +153,54 @@ def run_attention(cfg, steps, warmup, device, dist=None, version="auto"):
     wall, ev = time_gpu(step, steps, warmup, dist)
     nbytes = attention_bytes(S, ctx, H, KVH, D, BS, 1 if fp8 else 2)
     return dict(wall=wall, event=ev, bytes=nbytes)
+
+
+def run_attention_shape(name, S, ctx, H, KVH, device, dist=None, world=1, iters=20, D=128, BS=16):
+    """One fp8-KV decode shape through PagedAttention.forward_decode, HIP-event timed (max over
+    ranks when distributed); bytes = K and V once + q / out + tables (per rank)."""
+    from vllm_amd.attention.paged_attn import PagedAttention
+    q, caches, bt, sl, one = make_attention_inputs(S, ctx, H, KVH, D, BS, True, device, n_caches=1)
+    kc, vc = caches[0]
+    fn = lambda: PagedAttention.forward_decode(q, kc, vc, bt, sl, ctx, "fp8", KVH, D ** -0.5, None,
+                                               one, one)
+    _, ev = time_gpu(fn, iters, 3, dist)
+    if dist is not None:
+        t = torch.tensor([ev], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ev = t.item()
+    per = ev / iters
+    nbytes = attention_bytes(S, ctx, H, KVH, D, BS, 1)
+    del kc, vc, caches
+    torch.cuda.empty_cache()
+    return dict(shape=f"{name}: {S} seqs x ctx {ctx}, {H}q/{KVH}kv heads per GPU, fp8 KV",
+                us=round(per * 1e6, 1), gbps_per_gpu=round(nbytes / per / 1e9, 1),
+                gbps_total=round(world * nbytes / per / 1e9, 1),
+                frac_of_hbm_peak=round(nbytes / per / 1e9 / HBM_PEAK_GBPS, 4))
+
+
+def run_ragged_decode(device, iters=20):
+    """configs[1] head shape with ragged lengths U[512, 4096] (seeded): bytes = what the
+    sequences actually hold."""
+    from vllm_amd.attention.paged_attn import PagedAttention
+    S, ctx, H, KVH, D, BS = 64, 4096, 32, 8, 128, 16
+    q, caches, bt, sl, one = make_attention_inputs(S, ctx, H, KVH, D, BS, True, device, n_caches=2)
+    g = torch.Generator().manual_seed(0)
+    lens = torch.randint(512, ctx + 1, (S,), generator=g).to(torch.int32)
+    sl = lens.to(device)
+    max_len = int(lens.max())
+    state = {"i": 0}
+
+    def fn():
+        kc, vc = caches[state["i"] % 2]
+        state["i"] += 1
+        return PagedAttention.forward_decode(q, kc, vc, bt, sl, max_len, "fp8", KVH, D ** -0.5, None,
+                                             one, one)
+    _, ev = time_gpu(fn, iters, 3)
+    per = ev / iters
+    nbytes = int(lens.sum()) * KVH * D * 2 + S * H * D * 4 + int(((lens + BS - 1) // BS).sum()) * 4 + 4 * S
+    return dict(shape="64 seqs x U[512,4096] tokens, 32q/8kv, fp8 KV", us=round(per * 1e6, 1),
+                gbps=round(nbytes / per / 1e9, 1),
+                frac_of_hbm_peak=round(nbytes / per / 1e9 / HBM_PEAK_GBPS, 4))
 
 
 def run_scaled_mm(device, shapes, Ms, iters=20):
@@ -432,15 +487,66 @@ def cpu_baseline_port(budget_s=8.0):
                        f"16): oracle/oracle.c paged_attention_v1, {n} iterations in {el:.1f} s")
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks (one per GPU) from this
+    parent, which has not touched a GPU (device_count() does not initialise one), rendezvous on
+    127.0.0.1, and return non-zero if any rank fails."""
+    import socket
+    import subprocess
+    if "--dry-run-backend" not in " ".join(sys.argv):
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        if p.wait() != 0:
+            rc = 1
+    return rc
+
+
+def dry_run(args):
+    """CPU rehearsal of the N-rank launch path (tests): rendezvous, one all-reduce, rank 0 prints."""
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group(args.dry_run_backend, rank=rank, world_size=world)
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    ok = int(t.item()) == world and dist.get_world_size() == args.gpus
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": dist.get_world_size(), "sum": t.item()}), flush=True)
+    dist.destroy_process_group()
+    return 0 if ok else 2
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-extra", action="store_true", help="skip scaled_mm / cache / cpu legs")
+    ap.add_argument("--dry-run-backend", default=None,
+                    help="(tests) 'gloo': ranks only rendezvous on the CPU and rank 0 prints a stub line")
     args = ap.parse_args()
 
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run_backend:
+        sys.exit(dry_run(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -455,6 +561,9 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != world:
+            print(f"bench.py: RCCL world size {dist.get_world_size()} != {world}", file=sys.stderr)
+            sys.exit(2)
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
 
@@ -473,10 +582,15 @@ def main():
     per_launch = ev / args.steps
     achieved = r["bytes"] / per_launch / 1e9
 
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_attention_pmc.json")
-    if os.path.exists(pmc):   # HBM bytes per launch from committed rocprofv3 PMC passes
-        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+    # HBM bytes per launch: from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
+    # profiles/), not re-measured in this run
+    traffic, traffic_src = None, None
+    for name in ("r02_attention_pmc.json", "r01_attention_pmc.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            traffic_src = "profiles/" + name + " (committed rocprofv3 --pmc passes, not this run)"
+            break
 
     line = {
         "metric": "paged-attn decode HBM GB/s (% peak) + fp8 scaled_mm TFLOPS at 1/2/4/8 GPUs",
@@ -499,6 +613,7 @@ def main():
         "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBPS, 2),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "traffic_source": traffic_src,
                      "kernel": "pa_mfma_kernel<bf16, fp8, 128, 16>",
                      "us_per_launch": round(per_launch * 1e6, 2),
                      "algorithmic_bytes_per_launch": r["bytes"]},
@@ -516,12 +631,28 @@ def main():
             extra["fused_neighbours"] = run_fused_neighbours(device)
             extra["prefill_attention"] = run_prefill(device)
             extra["unified_decode"] = run_unified_decode(device)
+            # the single-GPU shapes of configs[3] / configs[4] and a ragged configs[1] batch
+            extra["configs3_per_gpu"] = run_attention_shape("configs[3] per-GPU", 256, 32768, 8, 1, device)
+            extra["configs4_n1"] = run_attention_shape("configs[4] at N=1", 8, 131072, 64, 8, device)
+            extra["ragged_decode"] = run_ragged_decode(device)
             line["cpu_baseline"] = cpu_baseline()
             # same workload as `value` (fp8 KV), which the reference's CPU kernel cannot run
             line["cpu_baseline_port"] = cpu_baseline_port()
         line["extra"] = extra
     if use_dist:
         from vllm_amd.distributed import bench_row_parallel
+        ex = {}
+        try:
+            if 8 % world == 0:
+                ex["configs4_strong"] = run_attention_shape(
+                    f"configs[4] strong-scaled over {world} GPUs", 8, 131072, 64 // world, 8 // world,
+                    device, dist, world)
+            ex["configs3_per_gpu"] = run_attention_shape("configs[3] per-GPU", 256, 32768, 8, 1,
+                                                         device, dist, world)
+        except Exception as e:
+            ex["attention_error"] = f"{type(e).__name__}: {e}"
+        if rank == 0:
+            line.setdefault("extra", {}).update(ex)
         try:
             rp = bench_row_parallel(device, dist)
         except Exception as e:   # the headline line must still be printed

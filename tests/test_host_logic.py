@@ -175,3 +175,23 @@ def test_v1_backend_host_logic():
     impl = TritonAttentionImpl(32, 64, 0.25, 8, None, None, "auto")
     assert impl.sliding_window == (-1, -1) and impl.logits_soft_cap == 0 and impl.alibi_slopes is None
     assert impl.fused_output_quant_supported(torch.float8_e4m3fn, True, (-1, -1))
+
+
+def test_bench_self_launch_two_ranks_gloo():
+    """`python bench.py --gpus 2` with no launcher spawns its own ranks (127.0.0.1 rendezvous) and
+    fails loudly when the world does not match: rehearsed on the CPU with gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+                        "--dry-run-backend", "gloo"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["sum"] == 2.0
+    env2 = dict(env, WORLD_SIZE="2", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4",
+                        "--dry-run-backend", "gloo"], env=env2, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
