@@ -70,6 +70,19 @@ def test_scaled_mm_llama_shapes(ops, oracle, KN, M):
     check(ops, oracle, M, N, K, True, True, torch.bfloat16, False, seed=K + M)
 
 
+@pytest.mark.parametrize("K", [1024, 3584])
+def test_scaled_mm_configs3_row_parallel_shapes(ops, oracle, K):
+    """configs[3]: the per-GPU row-parallel GEMMs of the TP=8 Llama-3-70B shard (o_proj K 1024,
+    down_proj K 3584 -> hidden 8192, M 256; weight_shapes.py:58-63 / 8), per-token x per-channel."""
+    check(ops, oracle, 256, 8192, K, True, True, torch.bfloat16, False, seed=K)
+
+
+@pytest.mark.parametrize("M", [1, 16])
+def test_scaled_mm_gate_up_shape_small_m(ops, oracle, M):
+    """configs[2]: (K 4096, N 28672) at decode batch sizes."""
+    check(ops, oracle, M, 28672, 4096, True, True, torch.bfloat16, False, seed=M)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4])
 @pytest.mark.parametrize("mk", [(256, 1024), (4096, 4096), (1000, 512)])
 def test_wvSplitKQ(ops, oracle, n, mk):

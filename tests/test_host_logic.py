@@ -195,3 +195,64 @@ def test_bench_self_launch_two_ranks_gloo():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4",
                         "--dry-run-backend", "gloo"], env=env2, capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_plugin_entry_point_metadata(tmp_path):
+    """setup.py declares the `vllm.general_plugins` entry point the reference's plugin
+    loader scans (vllm/plugins/__init__.py:19-81; packaging pattern of
+    tests/plugins/vllm_add_dummy_platform/setup.py): build the metadata, discover the entry
+    point through importlib.metadata as vLLM does, load and call it."""
+    import importlib.metadata as md
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "setup.py", "-q", "egg_info", "--egg-base", str(tmp_path)],
+                       cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    dists = list(md.distributions(path=[str(tmp_path)]))
+    assert len(dists) == 1 and dists[0].metadata["Name"] in ("vllm_amd", "vllm-amd")
+    eps = [e for e in dists[0].entry_points if e.group == "vllm.general_plugins"]
+    assert [e.name for e in eps] == ["vllm_amd"] and eps[0].value == "vllm_amd.plugin:register"
+    register = eps[0].load()
+    register()     # imports the op layer: the schemas are registered under the reference's names
+    import torch
+    for ns, op in (("_C", "paged_attention_v1"), ("_C", "cutlass_scaled_mm"),
+                   ("_C_cache_ops", "reshape_and_cache"), ("_rocm_C", "paged_attention")):
+        assert hasattr(getattr(torch.ops, ns), op)
+
+
+def test_block_table_host_inputs_match_reference_arithmetic():
+    """BlockTable.compute_slot_mapping with the numpy inputs the reference's model runner passes
+    (block_table.py:84-99): host path, slot_mapping_np / slot_mapping_cpu filled, no device op."""
+    import numpy as np
+    from vllm_amd.worker import BlockTable
+    bt = BlockTable(16, 4, 8, 64, False, torch.device("cpu"))
+    bt.add_row([5, 9, 2], 0)
+    bt.add_row([7, 1], 2)
+    req = np.array([0, 0, 0, 2, 2], dtype=np.int32)
+    pos = np.array([0, 17, 40, 3, 31], dtype=np.int64)
+    bt.compute_slot_mapping(req, pos)
+    want = np.array([5 * 16, 9 * 16 + 1, 2 * 16 + 8, 7 * 16 + 3, 1 * 16 + 15])
+    assert (bt.slot_mapping_np[:5] == want).all() and (bt.slot_mapping_cpu[:5].numpy() == want).all()
+    bt.commit_slot_mapping(5)
+    assert (bt.slot_mapping[:5].numpy() == want).all()
+
+
+def test_fp8_linear_static_zero_dim_scale_is_not_sliced(monkeypatch):
+    """Static activation quantisation hands a 0-dim input_scale through (w8a8_utils.py:370-377);
+    slicing it would raise IndexError."""
+    from vllm_amd import quantization as Q
+    seen = {}
+
+    def fake_mm(a, b, sa, sb, out_dtype, bias=None):
+        seen["sa"] = sa
+        return torch.zeros((a.shape[0], b.shape[1]), dtype=out_dtype)
+
+    monkeypatch.setattr(Q.ops, "cutlass_scaled_mm", fake_mm)
+    op = Q.Fp8LinearOp(act_quant_static=True)
+    monkeypatch.setattr(op, "quant_fp8", lambda x, s, ub: (x.to(torch.float8_e4m3fn), s))
+    scale = torch.tensor(0.5)          # 0-dim, as Parameter(input_scale.max())
+    out = op.apply(torch.zeros((3, 32), dtype=torch.bfloat16), torch.zeros((32, 16), dtype=torch.float8_e4m3fn),
+                   torch.ones(16, 1), input_scale=scale)
+    assert out.shape == (3, 16) and seen["sa"] is scale

@@ -64,9 +64,14 @@ class Fp8LinearOp:
             qinput, x_scale = self.quant_fp8(input_2d, input_scale, input_scale_ub)
         else:
             qinput, x_scale = input_2d, input_scale
-        out = ops.cutlass_scaled_mm(qinput[:input_2d.shape[0]] if qinput.shape[0] != input_2d.shape[0] else qinput,
-                                    weight, x_scale[:input_2d.shape[0]], weight_scale, out_dtype,
-                                    bias)
+        m = input_2d.shape[0]
+        if qinput.shape[0] != m:           # num_token_padding rows
+            qinput = qinput[:m]
+        # per-token scales may carry the padding rows; a per-tensor scale (static quantisation:
+        # a 0-dim or 1-element tensor, w8a8_utils.py:370-377) passes through untouched
+        if x_scale.numel() > 1 and x_scale.shape[0] != m:
+            x_scale = x_scale[:m]
+        out = ops.cutlass_scaled_mm(qinput, weight, x_scale, weight_scale, out_dtype, bias)
         return out.view(*output_shape)
 
 
