@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvllm_amd.so")
+# VLLM_AMD_LIB: another build of the SAME library (tools/: the -DVA_PROBES measurement build)
+LIB_PATH = os.environ.get("VLLM_AMD_LIB") or os.path.join(_HERE, "csrc", "libvllm_amd.so")
 
 F32, F16, BF16 = 0, 1, 2
 KV_AUTO, KV_FP8_E4M3 = 0, 1

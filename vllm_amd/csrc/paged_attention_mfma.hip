@@ -37,6 +37,28 @@
 namespace va {
 
 constexpr int kDefaultVariant = 1;   // set from measurements, see DESIGN.md
+
+// tools/pa_probe.hip compiles this file with -DVA_PROBES: per-workgroup time stamps (100 MHz
+// s_memrealtime) and two ablations (VARIANT bit 2 = loads only, bit 3 = no cross-wave merge).
+// Nothing of it exists in the library build.
+#ifdef VA_PROBES
+// the stamps stay in SGPRs until the kernel's last instruction: a global store in front of the
+// block-table loads would turn them from scalar into vector loads (no longer provably unclobbered)
+__device__ unsigned long long g_pa_stamps[16384 * 4];
+#define VA_STAMP_DECL unsigned long long va_stamp_[4] = {0, 0, 0, 0}
+#define VA_STAMP(i) va_stamp_[i] = __builtin_amdgcn_s_memrealtime()
+#define VA_STAMP_FLUSH()                                                                  \
+  do {                                                                                    \
+    va_stamp_[3] = __builtin_amdgcn_s_memrealtime();                                      \
+    if (threadIdx.x == 0)                                                                 \
+      for (int i_ = 0; i_ < 4; ++i_)                                                      \
+        g_pa_stamps[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 4 + i_] = va_stamp_[i_]; \
+  } while (0)
+#else
+#define VA_STAMP_DECL do { } while (0)
+#define VA_STAMP(i) do { } while (0)
+#define VA_STAMP_FLUSH() do { } while (0)
+#endif
 constexpr int kPRowBytes = 144;  // P tile row (one q head): 64 tok * 2 B + 16 B pad
 
 // VARIANT bit 0: non-temporal K/V loads; bit 1: two steps of K/V registers in flight
@@ -57,6 +79,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
     int64_t kv_head_bytes, const float* __restrict__ k_scale_p,
     const float* __restrict__ v_scale_p, int partition_size, int max_parts, int gqa_chunks,
     int slot_stride, int dr_arg) {
+  VA_STAMP_DECL;
+  VA_STAMP(0);
   const int dr = PAD ? dr_arg : HEAD_SIZE;
   constexpr int ES = FP8 ? 1 : 2;             // cache element bytes
   constexpr int TILES = FP8 ? 4 : 2;          // 16-token tiles per step
@@ -122,13 +146,18 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
   constexpr int QF = HEAD_SIZE / 32;  // k-steps of the QK product
   uint4 qf[QF];
   {
-    const scalar_t* qp = q + qrow * q_stride + (int64_t)(head0 + c16) * dr;
+    // Unconditional loads from clamped addresses, no select: a lane without a q head (c16 >=
+    // nheads) carries the group's first head, its column of S^T / O^T is computed and never
+    // stored; a padded d chunk (d >= dr) carries q[0..7], which only ever meets zero K chunks.
+    // With a branch around these loads hipcc cannot count the outstanding loads and drains them
+    // all -- V included -- in front of the first MFMA of every step.
+    const scalar_t* qp = q + qrow * q_stride + (int64_t)(head0 + (col_ok ? c16 : 0)) * dr;
 #pragma unroll
     for (int s = 0; s < QF; ++s) {
       int d;
       if constexpr (FP8) d = 16 * (g4 + 4 * (s >> 1)) + 8 * (s & 1);
       else d = 8 * (g4 + 4 * s);
-      qf[s] = (col_ok && (!PAD || d < dr)) ? *reinterpret_cast<const uint4*>(qp + d) : make_uint4(0, 0, 0, 0);
+      qf[s] = *reinterpret_cast<const uint4*>(qp + ((!PAD || d < dr) ? d : 0));
     }
   }
 
@@ -143,8 +172,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
   constexpr bool DEEP = (VARIANT & 2) != 0;
   typedef uint4 KRegs[TILES * KL];
   typedef uint4 VRegs[DT];
-  KRegs kregA, kregB;
-  VRegs vregA, vregB;
+  KRegs kregA;
+  VRegs vregA;
   auto ld16 = [&](const uint8_t* p) -> uint4 {
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     const u32x4* q4 = reinterpret_cast<const u32x4*>(p);
@@ -196,8 +225,24 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
 
   // one step of the online-softmax recurrence on the registers of (kreg, vreg);
   // `pf` = the step whose K/V are loaded into the same registers once they are free
-  auto do_step = [&](KRegs& kreg, VRegs& vreg, int step, int pf) {
+  auto do_step = [&](KRegs& kreg, VRegs& vreg, int step, int pf, auto more_c) {
+    constexpr bool more = decltype(more_c)::value;   // this step is followed by step pf of the wave
     const int tok0 = start_tok + step * STEP_TOK;
+#ifdef VA_PROBES
+    if constexpr ((VARIANT & 4) != 0) {   // ablation: the loads and their issue points only
+      uint4 x = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TILES * KL; ++i) { x.x ^= kreg[i].x; x.y ^= kreg[i].y; x.z ^= kreg[i].z; x.w ^= kreg[i].w; }
+      if (step == 0) VA_STAMP(1);
+      if (more) issue_k(kreg, pf);
+#pragma unroll
+      for (int m = 0; m < DT; ++m) { x.x ^= vreg[m].x; x.y ^= vreg[m].y; x.z ^= vreg[m].z; x.w ^= vreg[m].w; }
+      if (more) issue_v(vreg, pf);
+      o[0][0] += __uint_as_float((x.x ^ x.y ^ x.z ^ x.w) & 0x3f000000u);
+      (void)tok0;
+      return;
+    }
+#endif
     // ---------------- S^T = K Q^T -------------------------------------------------
     f32x4 s[TILES];
 #pragma unroll
@@ -216,8 +261,10 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
       }
       s[t] = acc;
     }
-    const bool more = pf < nsteps;
-    if (more) issue_k(kreg, pf);
+    if constexpr (more) issue_k(kreg, pf);
+#ifdef VA_PROBES
+    if (step == 0) VA_STAMP(1);   // wave 0: its first K tiles have been consumed
+#endif
 
     // ---------------- online softmax ----------------------------------------------
     // lane holds S^T[token = tok0 + 16 t + 4 g4 + r][q head c16]
@@ -297,20 +344,38 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
         o[m] = Mma<scalar_t>::mfma(raw, plo, o[m]);
       }
     }
-    if (more) issue_v(vreg, pf);
+    if constexpr (more) issue_v(vreg, pf);
   };
+  const std::true_type MORE;
+  const std::false_type LAST;
 
   if (wave < nsteps) { issue_k(kregA, wave); issue_v(vregA, wave); }
-  if constexpr (DEEP) {
-    if (wave + NW < nsteps) { issue_k(kregB, wave + NW); issue_v(vregB, wave + NW); }
-    for (int step = wave; step < nsteps; step += 2 * NW) {
-      do_step(kregA, vregA, step, step + 2 * NW);
-      if (step + NW < nsteps) do_step(kregB, vregB, step + NW, step + 3 * NW);
-    }
-  } else {
-    for (int step = wave; step < nsteps; step += NW) do_step(kregA, vregA, step, step + NW);
+  // Retire q (requested before the block-table chain, long arrived) here, behind the join, where
+  // hipcc drains the counter completely -- the first step waits for its V as well as its K,
+  // once.  With q still pending in its model at the loop head, or retired by a counted wait
+  // (vmcnt(16), which its loop analysis does not carry over the back edge), it drains EVERY
+  // outstanding load, V included, in front of the first MFMA of every step; after a full drain
+  // the loop waits for exactly the load each MFMA consumes (vmcnt(15) .. vmcnt(8)).
+#pragma unroll
+  for (int s = 0; s < QF; ++s) asm volatile("" ::"v"(qf[s].x), "v"(qf[s].y), "v"(qf[s].z), "v"(qf[s].w));
+  static_assert(!DEEP, "the two-register-set variant was measured slower (profiles/r01_ab_attention.txt) and is gone");
+  {
+    // every step but the wave's last issues the loads of its successor unconditionally (no
+    // branch around a load: hipcc then counts the outstanding loads exactly instead of draining
+    // them all before the first MFMA of a step)
+    int step = wave;
+    for (; step + NW < nsteps; step += NW) do_step(kregA, vregA, step, step + NW, MORE);
+    if (step < nsteps) do_step(kregA, vregA, step, step + NW, LAST);
   }
 
+  VA_STAMP(2);
+#ifdef VA_PROBES
+  if constexpr ((VARIANT & 8) != 0) {   // ablation: no merge, every wave stores something
+    out[((int64_t)qrow * num_heads + head0 + c16) * dr + wave * 32 + g4 * 8] = (scalar_t)(o[0][0] + l_run + m_run);
+    VA_STAMP_FLUSH();
+    return;
+  }
+#endif
   // ---------------- merge the NW waves ------------------------------------------------
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
@@ -373,6 +438,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
     }
     *reinterpret_cast<uint4*>(out + oidx) = pk;
   }
+  VA_STAMP_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------
@@ -403,7 +469,11 @@ static int pa_variant() {
   }
   return g_pa_variant;
 }
+#ifdef VA_PROBES
+void set_pa_variant(int v) { g_pa_variant = v & 15; }
+#else
 void set_pa_variant(int v) { g_pa_variant = v & 3; }
+#endif
 static int g_pa_sp = 0;
 void set_pa_sp(int v) { g_pa_sp = v; }
 static int g_pa_group = 0;
@@ -441,6 +511,10 @@ static int launch_mfma(const PagedAttnParams& p) {
   // bit 1 (two register sets in flight) measured 1% slower than bit 0 alone on
   // configs[1] (profiles/r01_ab_attention.txt) and is not instantiated
   const bool nt = (pa_variant() & 1) != 0;
+#ifdef VA_PROBES
+  if constexpr (FP8 && HS == 128 && BS == 16)
+    if ((pa_variant() & 4) && p.head_size == HS) return launch_mfma_v<scalar_t, FP8, HS, BS, 5, false>(p);
+#endif
   if (p.head_size != HS)   // padded head sizes: non-temporal loads only
     return launch_mfma_v<scalar_t, FP8, HS, BS, 1, true>(p);
   return nt ? launch_mfma_v<scalar_t, FP8, HS, BS, 1, false>(p)
@@ -493,3 +567,9 @@ int paged_attention_mfma(const PagedAttnParams& p0) {
 }
 
 }  // namespace va
+
+#ifdef VA_PROBES
+extern "C" int vllm_amd_probe_stamps(unsigned long long* dst, int nwg) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(va::g_pa_stamps), (size_t)nwg * 4 * 8) == hipSuccess ? 0 : -3;
+}
+#endif
