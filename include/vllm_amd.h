@@ -190,17 +190,20 @@ int vllm_amd_scaled_mm(void* out, const void* a, const void* b,
                        int64_t ldb, int64_t ldc, int a_scale_numel,
                        int b_scale_numel, int out_dtype, void* stream);
 
-/* No counterpart in the reference (its GEMM libraries own their workspaces): registers
- * (ws != NULL) or removes (ws == NULL) the CURRENT device's split-K workspace of
- * vllm_amd_scaled_mm -- `bytes` of caller-owned device memory, 256-byte aligned, valid until
- * replaced or removed; at least 64 KiB + 1 KiB, useful from 64 KiB + 4 x 2 MiB.  Its ticket
- * counters are zeroed on `stream` (asynchronously: order the first GEMM behind it).  Without a
- * workspace every GEMM runs unsplit.  With one, the few shapes the heuristic splits (M <= 64,
- * K >= 12288, <= 128 tiles of 64 x 32) reduce their K slices in-kernel through it: the
- * workspace is cut into 4 slots, a slot belongs to the first stream that asks for it, launches
- * of one stream share their slot (they are ordered), a fifth stream, a launch under stream
- * capture and a launch that needs more than a slot run unsplit. */
-int vllm_amd_scaled_mm_set_workspace(void* ws, int64_t bytes, void* stream);
+/* No counterpart in the reference (its libraries own their workspaces): registers (ws != NULL)
+ * or removes (ws == NULL) the CURRENT device's workspace -- `bytes` of caller-owned device
+ * memory, 256-byte aligned, valid until replaced or removed; at least 513 KiB, sized for full use
+ * at 512 KiB + 4 x 16 MiB.  Its ticket counters are zeroed on `stream` (asynchronously: order
+ * the first op behind it).  Nothing is ever allocated inside an op call; the kernels that want
+ * device scratch beyond their arguments take it from here and run their scratch-free form
+ * without it:
+ *   vllm_amd_scaled_mm           the few shapes its heuristic splits over K (M <= 64, K >= 12288)
+ *   vllm_amd_paged_attention_v1  the opt-in balanced work distribution for skewed batches
+ *                                (tuning "pa_balance" = 1; the op has no scratch arguments)
+ * The workspace is cut into 4 slots; a slot belongs to the first stream that asks for it,
+ * launches of one stream share their slot (they are ordered), a fifth stream, a launch under
+ * stream capture and a launch that needs more than a slot use the scratch-free form. */
+int vllm_amd_set_workspace(void* ws, int64_t bytes, void* stream);
 
 /* No counterpart in the reference.  The ONE entry point for callers that cannot allocate or
  * register device memory (code under HIP-graph capture, tight serving loops, harnesses that
@@ -377,6 +380,9 @@ int vllm_amd_unified_attention(
 /*                 launches (0 = heuristic, paged_attention_mfma.hip)          */
 /*   "pa_group":   XCD-grouped workgroup order of the decode kernel (0 = heuristic:   */
 /*                 >= 1024 workgroups and >= 2 kv heads, 1 = always, 2 = never)     */
+/*   "pa_balance": 1 = paged_attention_v1 cuts the concatenated sequences into equal    */
+/*                 ranges, two workgroups per CU, and merges shared sequences through   */
+/*                 the registered workspace (pays on skewed batches only; default 0)    */
 /*   "mm_kernel":  scaled_mm kernel for M > 32: 0 = heuristic, 1 = register-   */
 /*                 staged 128x128 tile, 2..10 = direct-to-LDS tile shapes       */
 /*                 (256x256, 128x128, 128x64, 64x64, 64x32; even ids 4..10      */
@@ -391,7 +397,7 @@ int vllm_amd_unified_attention(
 /*   "mm_splitk":  K slices per output tile of the direct-to-LDS kernels        */
 /*                 (0 = heuristic, 1 = never split, n = n slices; reduced       */
 /*                 inside the kernel through the registered workspace,          */
-/*                 vllm_amd_scaled_mm_set_workspace; unsplit without one)       */
+/*                 vllm_amd_set_workspace; unsplit without one)                 */
 /* ------------------------------------------------------------------------- */
 int vllm_amd_set_tuning(const char* key, int value);
 

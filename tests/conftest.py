@@ -24,3 +24,13 @@ def oracle():
     from oracle import oracle as O
     O.lib()
     return O
+
+
+@pytest.fixture(params=["balanced", "plain"])
+def v1_form(request):
+    """paged_attention_v1 has two launch forms: one workgroup per (sequence, kv head) (default)
+    and balanced over the registered workspace ("pa_balance" = 1)."""
+    from vllm_amd import _lib
+    _lib.set_tuning("pa_balance", 0 if request.param == "plain" else 1)
+    yield request.param
+    _lib.set_tuning("pa_balance", 0)

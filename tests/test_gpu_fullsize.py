@@ -114,10 +114,23 @@ def test_fullsize_decode(ops, oracle, case, ragged):
     out2 = decode(c, v_scale=c["sc"] * 2)
     assert torch.equal(out2.float(), out.float() * 2)
 
-    # (4) permuting the batch permutes the rows bit for bit
+    # (4) permuting the batch permutes the rows bit for bit (every sequence is summed by one
+    # workgroup in a fixed order)
     p = torch.randperm(S, device="cuda")
     outp = decode(c, q=c["q"][p].contiguous(), bt=c["bt"][p].contiguous(), sl=c["sl"][p].contiguous())
     assert torch.equal(outp, out[p])
+
+    # (5) the balanced v1 form ("pa_balance" = 1) cuts a ragged batch where the order of the
+    # sequences puts the cuts: same rows within the tolerance, in either order
+    from vllm_amd import _lib
+    _lib.set_tuning("pa_balance", 1)
+    try:
+        bal = decode(c)
+        balp = decode(c, q=c["q"][p].contiguous(), bt=c["bt"][p].contiguous(), sl=c["sl"][p].contiguous())
+    finally:
+        _lib.set_tuning("pa_balance", 0)
+    torch.testing.assert_close(bal.float(), out.float(), atol=ATOL, rtol=1e-5)
+    torch.testing.assert_close(balp.float(), out[p].float(), atol=ATOL, rtol=1e-5)
 
 
 def test_fullsize_cache_write_roundtrip(ops, oracle):

@@ -70,7 +70,9 @@ SEQ_LENS = [1, 15, 16, 17, 63, 64, 65, 300, 513, 1029]
 @pytest.mark.parametrize("kv", ["auto", "fp8"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("heads", [(32, 8), (8, 1), (5, 5), (16, 1)])
-def test_mfma_path(ops, oracle, version, kv, dtype, heads):
+def test_mfma_path(ops, oracle, version, kv, dtype, heads, v1_form):
+    if version != "v1" and v1_form == "plain":
+        pytest.skip("the launch form only concerns v1")
     H, KVH = heads
     c = make_attn_case(len(SEQ_LENS), H, KVH, 128, 16, dtype, kv, SEQ_LENS, seed=H,
                        kv_scale=1.0 if kv == "auto" else 0.5)
@@ -103,7 +105,9 @@ def test_generic_path(ops, oracle, version, kv, dtype, hs_bs):
 @pytest.mark.parametrize("version", ["v1", "v2"])
 @pytest.mark.parametrize("kv", ["auto", "fp8"])
 @pytest.mark.parametrize("hs_bs", [(32, 32), (80, 32), (96, 16), (112, 32), (120, 16)])
-def test_mfma_padded_head_sizes(ops, oracle, version, kv, hs_bs):
+def test_mfma_padded_head_sizes(ops, oracle, version, kv, hs_bs, v1_form):
+    if version != "v1" and v1_form == "plain":
+        pytest.skip("the launch form only concerns v1")
     """head sizes below 64 / 128 run the MFMA kernel padded (absent chunks never loaded);
     GQA 4:1 and contexts past one partition (reference HEAD_SIZES, test_attention.py:33)."""
     hs, bs = hs_bs
@@ -208,7 +212,9 @@ _GOLD = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
 @pytest.mark.parametrize("path", sorted(_glob.glob(_os.path.join(_GOLD, "attnfp8_ref_*.pt"))),
                          ids=lambda p: _os.path.basename(p))
 @pytest.mark.parametrize("version", ["v1", "v2", "rocm"])
-def test_fp8kv_reference_executed_golden(ops, path, version):
+def test_fp8kv_reference_executed_golden(ops, path, version, v1_form):
+    if version != "v1" and v1_form == "plain":
+        pytest.skip("the launch form only concerns v1")
     """HIP fp8-KV decode (k_scale != v_scale) against outputs the reference's own CPU kernels
     produced on the per-element dequantised cache (tests/golden/make_golden.py attention_fp8kv;
     the route of the reference's test, test_attention.py:306-322).  Tolerance: the reference's for
@@ -240,3 +246,52 @@ def test_fp8kv_reference_executed_golden(ops, path, version):
     torch.cuda.synchronize()
     torch.testing.assert_close(out.cpu().float(), want.float(), atol=1e-2, rtol=1e-5)
     assert (out.cpu().float() - want.float()).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("lens", [
+    [4096, 1, 64, 65, 700, 3000, 17],             # one long sequence shared by many workgroups
+    [100] * 40 + [5000],                          # many short sequences per workgroup + one long
+    [64] * 3,                                     # fewer steps than workgroups
+    [8192],                                       # a single sequence cut into every workgroup
+    [1029, 2050, 513, 4000, 300, 16, 15, 2048, 1024, 1, 640, 3333],
+])
+def test_v1_balanced_ragged(ops, oracle, kv, lens):
+    """Balanced v1 launches (paged_attention_mfma.hip): sequences shared between workgroups are
+    merged through the workspace by the last finisher; two launches in a row reuse the
+    self-resetting tickets; results equal the plain form within the stated tolerance."""
+    from vllm_amd import _lib
+    c = make_attn_case(len(lens), 32, 8, 128, 16, torch.bfloat16, kv, lens,
+                       seed=len(lens), kv_scale=1.0 if kv == "auto" else 0.5)
+    _lib.set_tuning("pa_balance", 1)
+    try:
+        for _ in range(2):
+            run_case(ops, oracle, c, "v1")
+    finally:
+        _lib.set_tuning("pa_balance", 0)
+    q, kc, vc, bt, sl = (to_dev(c[k]) for k in ("q", "kc", "vc", "bt", "sl"))
+    sc = torch.tensor([c["kv_scale"]], device="cuda")
+    outs = []
+    for form in (1, 0):
+        _lib.set_tuning("pa_balance", form)
+        o = torch.full_like(q, float("nan"))
+        ops.paged_attention_v1(o, q, kc, vc, 8, c["scale"], bt, sl, 16, c["max_len"], None, kv, sc, sc)
+        outs.append(o)
+    _lib.set_tuning("pa_balance", 0)
+    torch.cuda.synchronize()
+    assert not outs[0].isnan().any()
+    torch.testing.assert_close(outs[0].float(), outs[1].float(), atol=2e-3, rtol=1e-5)
+
+
+def test_v1_zero_length_sequences(ops, v1_form):
+    """seq_len 0: no key, exp_sum 0 -> the reference writes zeros (attention_kernels.cuh:337)."""
+    lens = [0, 5, 0, 130]
+    c = make_attn_case(4, 8, 2, 128, 16, torch.bfloat16, "fp8", [1, 5, 1, 130], seed=2, kv_scale=0.5)
+    q, kc, vc, bt = (to_dev(c[k]) for k in ("q", "kc", "vc", "bt"))
+    sl = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    sc = torch.tensor([0.5], device="cuda")
+    o = torch.full_like(q, float("nan"))
+    ops.paged_attention_v1(o, q, kc, vc, 2, c["scale"], bt, sl, 16, 130, None, "fp8", sc, sc)
+    torch.cuda.synchronize()
+    assert not o.isnan().any()
+    assert (o[0] == 0).all() and (o[2] == 0).all() and (o[1] != 0).any() and (o[3] != 0).any()

@@ -21,9 +21,14 @@ using namespace va;
 template <int VARIANT>
 static void launch(bf16_t* out, const bf16_t* q, const uint8_t* kc, const uint8_t* vc, const int* bt,
                    const int* sl, const float* one, int S, int H, int KVH, int max_blocks) {
-  hipLaunchKernelGGL((pa_mfma_kernel<bf16_t, true, 128, 16, 4, VARIANT, false>), dim3(S * KVH), dim3(256), 0, 0,
-                     out, nullptr, nullptr, q, kc, vc, H, KVH, 0.088f, bt, sl, nullptr, max_blocks, nullptr,
-                     (int64_t)H * 128, (int64_t)KVH * 2048, (int64_t)2048, one, one, 0, 1, 1, 1, 128);
+  PaK<bf16_t> A{};
+  A.out = out; A.q = q; A.k_cache = kc; A.v_cache = vc; A.num_heads = H; A.num_kv_heads = KVH;
+  A.scale = 0.088f; A.block_tables = bt; A.seq_lens = sl; A.max_num_blocks_per_seq = max_blocks;
+  A.q_stride = (int64_t)H * 128; A.kv_block_bytes = (int64_t)KVH * 2048; A.kv_head_bytes = 2048;
+  A.k_scale_p = one; A.v_scale_p = one; A.partition_size = 0; A.max_parts = 1; A.gqa_chunks = 1;
+  A.slot_stride = 1; A.dr_arg = 128; A.num_seqs = S;
+  hipLaunchKernelGGL((pa_mfma_kernel<bf16_t, true, 128, 16, 4, VARIANT, false, false>), dim3(S * KVH), dim3(256),
+                     0, 0, PA_ARGS(A));
 }
 
 int main(int argc, char** argv) {

@@ -41,7 +41,7 @@ SIGNATURES = {
     "vllm_amd_dynamic_per_token_scaled_fp8_quant": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "vllm_amd_scaled_mm": [
         _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _vp],
-    "vllm_amd_scaled_mm_set_workspace": [_vp, _i64, _vp],
+    "vllm_amd_set_workspace": [_vp, _i64, _vp],
     "vllm_amd_scaled_mm_static": [
         _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _i, _vp],
     "vllm_amd_wvSplitKQ": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

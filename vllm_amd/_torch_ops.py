@@ -77,6 +77,7 @@ def paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale, 
     _cuda(out, query, key_cache, value_cache, block_tables, seq_lens, alibi_slopes, k_scale, v_scale)
     num_seqs, num_heads, head_size = query.shape
     assert out.is_contiguous() and block_tables.dtype == torch.int32 and seq_lens.dtype == torch.int32
+    _ensure_workspace(query)
     with _dev(query):
         check(lib.vllm_amd_paged_attention_v1(
             _ptr(out), _ptr(query), _ptr(key_cache), _ptr(value_cache), num_seqs, num_heads,
@@ -336,29 +337,30 @@ def dynamic_per_token_scaled_fp8_quant(result, input, scale, scale_ub) -> None:
             _stream(input)))
 
 
-# Split-K workspace of vllm_amd_scaled_mm: the C ABI allocates nothing, so the op layer owns one
-# buffer per device (4 stream slots x 16 MiB of fp32 partials + ticket counters) and registers
-# it once, outside stream capture, before that device's first GEMM.  Without it every GEMM runs
-# unsplit (same results up to fp32 summation order).
-_MM_WS_BYTES = (64 << 20) + (64 << 10)
-_mm_ws = {}
+# The library workspace (vllm_amd_set_workspace): the C ABI allocates nothing, so the op layer
+# owns one buffer per device (4 stream slots x 16 MiB + ticket counters) and registers it once,
+# outside stream capture, before that device's first scaled_mm / paged_attention_v1.  Without it
+# the GEMM never splits over K and paged_attention_v1 runs one workgroup per (sequence, kv head)
+# (same results up to fp32 summation order).
+_WS_BYTES = (64 << 20) + (512 << 10)
+_ws = {}
 
 
-def _ensure_mm_workspace(t: torch.Tensor) -> None:
+def _ensure_workspace(t: torch.Tensor) -> None:
     idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
-    if idx in _mm_ws or torch.cuda.is_current_stream_capturing():
+    if idx in _ws or torch.cuda.is_current_stream_capturing():
         return
     with _dev(t):
-        buf = torch.empty(_MM_WS_BYTES, dtype=torch.uint8, device=t.device)
-        check(lib.vllm_amd_scaled_mm_set_workspace(_ptr(buf), _MM_WS_BYTES, _stream(t)))
+        buf = torch.empty(_WS_BYTES, dtype=torch.uint8, device=t.device)
+        check(lib.vllm_amd_set_workspace(_ptr(buf), _WS_BYTES, _stream(t)))
         # every stream's first launch must see the zeroed counters
         torch.cuda.current_stream(t.device).synchronize()
-    _mm_ws[idx] = buf
+    _ws[idx] = buf
 
 
 def cutlass_scaled_mm(out, a, b, a_scales, b_scales, bias) -> None:
     _cuda(out, a, b, a_scales, b_scales, bias)
-    _ensure_mm_workspace(a)
+    _ensure_workspace(a)
     # csrc/quantization/cutlass_w8a8/scaled_mm_entry.cu checks, restated
     if not (a.dim() == 2 and b.dim() == 2 and out.dim() == 2):
         raise RuntimeError("a.dim() == 2 && b.dim() == 2 && c.dim() == 2")

@@ -28,6 +28,22 @@ int hip_fail(hipError_t e, const char* what);
     if (e__ != hipSuccess) return ::va::hip_fail(e__, what); \
   } while (0)
 
+// ---- host side: the caller-registered workspace (vllm_amd_set_workspace) -----------------
+// Nothing is allocated inside an op call.  Kernels that need device scratch beyond their
+// arguments (split-K partials of scaled_mm, partials of the balanced decode attention) take it
+// from CALLER-OWNED memory registered per device; without one they run their scratch-free form.
+// The workspace is cut into WS_SLOTS slots; a slot belongs to ONE stream (the first that asks,
+// until the workspace is replaced): launches of one stream are ordered and may share a slot,
+// streams never share one.  No slot for: a stream beyond WS_SLOTS, a launch under stream capture
+// (the graph could replay on any stream, beside eager launches).  Ticket counters sit in their
+// own area, zeroed at registration, and every kernel leaves its counters at zero.
+constexpr int WS_SLOTS = 4;
+constexpr size_t WS_CTR_BYTES = (size_t)128 << 10;        // per slot
+constexpr size_t WS_CTR_MM_WORDS = 4096;                  // [0, 16 KiB): scaled_mm split-K tickets
+constexpr size_t WS_CTR_PA_WORDS = 28672;                 // [16 KiB, 128 KiB): decode attention tickets
+struct WsSlot { unsigned* ctr_mm; unsigned* ctr_pa; char* data; size_t data_bytes; };
+bool workspace_slot(hipStream_t st, WsSlot* out);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int dtype_size(int dt) { return dt == VLLM_AMD_F32 ? 4 : 2; }
 

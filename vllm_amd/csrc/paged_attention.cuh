@@ -42,6 +42,7 @@ int paged_attention_mfma(const PagedAttnParams& p);
 void set_pa_variant(int v);
 void set_pa_sp(int v);
 void set_pa_group(int v);
+void set_pa_balance(int v);
 // Split-K merge of partitions (v2 / rocm).
 int paged_attention_reduce(const PagedAttnParams& p);
 

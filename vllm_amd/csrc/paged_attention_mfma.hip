@@ -61,27 +61,58 @@ __device__ unsigned long long g_pa_stamps[16384 * 4];
 #endif
 constexpr int kPRowBytes = 144;  // P tile row (one q head): 64 tok * 2 B + 16 B pad
 
-// VARIANT bit 0: non-temporal K/V loads; bit 1: two steps of K/V registers in flight
+// kernel arguments
+template <typename scalar_t>
+struct PaK {
+  scalar_t* out; float* exp_sums; float* max_logits; const scalar_t* q;
+  const uint8_t* k_cache; const uint8_t* v_cache;
+  int num_heads, num_kv_heads; float scale;
+  const int* block_tables; const int* seq_lens; const int* query_start_loc;
+  int max_num_blocks_per_seq; const float* alibi_slopes;
+  int64_t q_stride, kv_block_bytes, kv_head_bytes;
+  const float* k_scale_p; const float* v_scale_p;
+  int partition_size, max_parts, gqa_chunks, slot_stride, dr_arg;
+  // balanced launches (BAL): partial slots, ticket counters, batch size
+  float* bal_ws; unsigned* bal_ctr; int num_seqs;
+};
+
+// What a workgroup does with one piece of one sequence: tokens [start_tok, end_tok) of `seq`.
+//   mode 0  the piece is the whole sequence: normalised result -> out
+//   mode 1  reference partition (v2 / rocm): normalised partial -> tmp_out slot, max / sum beside it
+//   mode 2  balanced launch, part of a sequence: unnormalised fp32 partial -> workspace slot, then a
+//           ticket; the workgroup that draws the sequence's last ticket merges all its pieces -> out
+struct PaPiece {
+  int seq; int64_t qrow; int start_tok, end_tok, seq_len; int mode; int part;
+  float* slot; const float* slots; unsigned* ticket; int jf, jl, pre, n_tot, gk;
+};
+
+template <int HEAD_SIZE> constexpr int pa_slot_floats() { return 16 * HEAD_SIZE + 32; }   // O[16][D], m[16], l[16]
+
+// VARIANT bit 0: non-temporal K/V loads
 // Partitioned launches (v2 / rocm): blockIdx.y = super-partition of `slot_stride` reference
 // partitions (partition_size = its token count); the partial result goes to scratch slot
 // blockIdx.y * slot_stride, the slots in between are not used (see launch_mfma_v).
 // PAD: the real head size `dr` is below HEAD_SIZE (a multiple of 8, of 16 with an fp8 cache): d
 // chunks / rows at d >= dr do not exist in the cache and are never loaded (zeros), output columns
 // there are never stored.
+#ifdef VA_PROBES
+#define VA_STAMP_PARAM , unsigned long long (&va_stamp_)[4]
+#define VA_STAMP_ARG , va_stamp_
+#else
+#define VA_STAMP_PARAM
+#define VA_STAMP_ARG
+#endif
 template <typename scalar_t, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int NW, int VARIANT, bool PAD>
-__global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
-    scalar_t* __restrict__ out, float* __restrict__ exp_sums, float* __restrict__ max_logits,
-    const scalar_t* __restrict__ q, const uint8_t* __restrict__ k_cache,
-    const uint8_t* __restrict__ v_cache, int num_heads, int num_kv_heads, float scale,
-    const int* __restrict__ block_tables, const int* __restrict__ seq_lens,
-    const int* __restrict__ query_start_loc, int max_num_blocks_per_seq,
-    const float* __restrict__ alibi_slopes, int64_t q_stride, int64_t kv_block_bytes,
-    int64_t kv_head_bytes, const float* __restrict__ k_scale_p,
-    const float* __restrict__ v_scale_p, int partition_size, int max_parts, int gqa_chunks,
-    int slot_stride, int dr_arg) {
-  VA_STAMP_DECL;
-  VA_STAMP(0);
-  const int dr = PAD ? dr_arg : HEAD_SIZE;
+__device__ __forceinline__ void pa_piece(const PaK<scalar_t>& A, char* lds, const PaPiece& P, int kvh,
+                                         int chunk VA_STAMP_PARAM) {
+  scalar_t* __restrict__ out = A.out;
+  const scalar_t* __restrict__ q = A.q;
+  const uint8_t* __restrict__ k_cache = A.k_cache;
+  const uint8_t* __restrict__ v_cache = A.v_cache;
+  const int num_heads = A.num_heads, num_kv_heads = A.num_kv_heads;
+  const int64_t q_stride = A.q_stride, kv_block_bytes = A.kv_block_bytes, kv_head_bytes = A.kv_head_bytes;
+  const float* __restrict__ alibi_slopes = A.alibi_slopes;
+  const int dr = PAD ? A.dr_arg : HEAD_SIZE;
   constexpr int ES = FP8 ? 1 : 2;             // cache element bytes
   constexpr int TILES = FP8 ? 4 : 2;          // 16-token tiles per step
   constexpr int STEP_TOK = TILES * 16;
@@ -94,38 +125,20 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c16 = lane & 15, g4 = lane >> 4;
-
-  // logical id = ((seq * num_kv_heads + kvh) * gqa_chunks + chunk), blockIdx.y = partition
-  int wg = blockIdx.x;
-  // Large launches: consecutive hardware ids go to different XCDs (id % 8); remapped so that the
-  // kv heads of a sequence -- adjacent pages of the same blocks -- stream through one XCD's L2
-  // (256 sequences x 8 kv heads x 4096 fp8: 330.6 -> 324.6 us; nothing at 512 workgroups)
-  if (slot_stride < 0) {
-    const int nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
-    wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    slot_stride = -slot_stride;
-  }
-  const int chunk = wg % gqa_chunks;
-  const int kvh = (wg / gqa_chunks) % num_kv_heads;
-  const int seq = wg / (gqa_chunks * num_kv_heads);
-  const int part = blockIdx.y;
   const int G = num_heads / num_kv_heads;
   const int head0 = kvh * G + chunk * 16;        // first q head of this workgroup
   const int nheads = min(16, G - chunk * 16);    // q heads served (columns in use)
 
-  int64_t qrow = seq;
-  if (query_start_loc) {
-    if (query_start_loc[seq + 1] - query_start_loc[seq] != 1) return;
-    qrow = query_start_loc[seq];
-  }
-  const int seq_len = seq_lens[seq];
-  const bool partitioned = partition_size > 0;
-  const int start_tok = partitioned ? part * partition_size : 0;
-  if (partitioned && start_tok >= seq_len) return;
-  const int end_tok = partitioned ? min(start_tok + partition_size, seq_len) : seq_len;
+  const int seq = P.seq;
+  const int64_t qrow = P.qrow;
+  const int seq_len = P.seq_len;
+  const int start_tok = P.start_tok, end_tok = P.end_tok;
   const int nsteps = (end_tok - start_tok + STEP_TOK - 1) / STEP_TOK;
   const int last_page = seq_len > 0 ? (seq_len - 1) / BLOCK_SIZE : 0;
-  const int* bt = block_tables + (int64_t)seq * max_num_blocks_per_seq;
+  const int* bt = A.block_tables + (int64_t)seq * A.max_num_blocks_per_seq;
+  const float scale = A.scale;
+  const float* k_scale_p = A.k_scale_p;
+  const float* v_scale_p = A.v_scale_p;
 
   float kscale = 1.f, vscale = 1.f;
   if constexpr (FP8) { kscale = *k_scale_p; vscale = *v_scale_p; }
@@ -137,7 +150,6 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
   constexpr int P_BYTES = 16 * kPRowBytes;                       // 2304
   constexpr int MERGE_BYTES = NW * HEAD_SIZE * 16 * 4 + NW * 16 * 8;
   constexpr int LDS_BYTES = (NW * P_BYTES > MERGE_BYTES) ? NW * P_BYTES : MERGE_BYTES;
-  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   char* p_tile = lds + wave * P_BYTES;
 
   // ---- Q^T fragments (B operand of QK), permuted like the K loads -------------
@@ -372,7 +384,6 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
 #ifdef VA_PROBES
   if constexpr ((VARIANT & 8) != 0) {   // ablation: no merge, every wave stores something
     out[((int64_t)qrow * num_heads + head0 + c16) * dr + wave * 32 + g4 * 8] = (scalar_t)(o[0][0] + l_run + m_run);
-    VA_STAMP_FLUSH();
     return;
   }
 #endif
@@ -410,33 +421,241 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
     float lt = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) lt += ml[(w * 16 + qh) * 2 + 1] * fast_exp2(ml[(w * 16 + qh) * 2] - mt);
-    const float inv = __fdividef(1.f, lt + 1e-6f) * vscale;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float a = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) a += om[(w * HEAD_SIZE + d0 + j) * 16 + qh];
-      acc[j] = a * inv;
+      acc[j] = a;
     }
-    uint4 pk;
-    pk.x = Mma<scalar_t>::pack2(acc[0], acc[1]);
-    pk.y = Mma<scalar_t>::pack2(acc[2], acc[3]);
-    pk.z = Mma<scalar_t>::pack2(acc[4], acc[5]);
-    pk.w = Mma<scalar_t>::pack2(acc[6], acc[7]);
-    const int head = head0 + qh;
-    int64_t oidx;
-    if (partitioned) {
-      const int64_t sidx = ((int64_t)seq * num_heads + head) * max_parts + (int64_t)part * slot_stride;
-      oidx = sidx * dr + d0;
+    if (P.mode == 2) {
+      // unnormalised partial (relative to mt) -> this piece's workspace slot, written through
+      float* so = P.slot + qh * HEAD_SIZE + d0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) __hip_atomic_store(so + j, acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (d0 == 0) {
-        max_logits[sidx] = mt * kLn2;
-        exp_sums[sidx] = lt;
+        __hip_atomic_store(P.slot + 16 * HEAD_SIZE + qh, mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.slot + 16 * HEAD_SIZE + 16 + qh, lt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
-      oidx = ((int64_t)qrow * num_heads + head) * dr + d0;
+      const float inv = __fdividef(1.f, lt + 1e-6f) * vscale;
+      uint4 pk;
+      pk.x = Mma<scalar_t>::pack2(acc[0] * inv, acc[1] * inv);
+      pk.y = Mma<scalar_t>::pack2(acc[2] * inv, acc[3] * inv);
+      pk.z = Mma<scalar_t>::pack2(acc[4] * inv, acc[5] * inv);
+      pk.w = Mma<scalar_t>::pack2(acc[6] * inv, acc[7] * inv);
+      const int head = head0 + qh;
+      int64_t oidx;
+      if (P.mode == 1) {
+        const int64_t sidx = ((int64_t)seq * num_heads + head) * A.max_parts + (int64_t)P.part * A.slot_stride;
+        oidx = sidx * dr + d0;
+        if (d0 == 0) {
+          A.max_logits[sidx] = mt * kLn2;
+          A.exp_sums[sidx] = lt;
+        }
+      } else {
+        oidx = ((int64_t)qrow * num_heads + head) * dr + d0;
+      }
+      *reinterpret_cast<uint4*>(out + oidx) = pk;
     }
-    *reinterpret_cast<uint4*>(out + oidx) = pk;
+  }
+  if (P.mode != 2) return;
+
+  // ---- balanced launch: ticket; the sequence's last piece merges all of them ---------------
+  // Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): every byte of a partial is an
+  // agent-scope (sc1, write-through) store; every storing wave drains its stores; one lane adds
+  // to the sequence's counter behind a workgroup barrier; the workgroup whose add came last
+  // reads every partial with agent-scope (sc1) loads after a barrier that lane has joined.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  volatile int* flag = reinterpret_cast<volatile int*>(lds + LDS_BYTES);
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(P.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = old == (unsigned)(P.jl - P.jf);
+    if (last) __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+    *flag = last;
+  }
+  __syncthreads();
+  if (*flag == 0) return;
+  if (qh < nheads && (!PAD || d0 < dr)) {
+    float M = -FLT_MAX, L = 0.f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    // four pieces per round: their loads (independent, ~2 us each through the fabric) are all
+    // issued before the first is combined; a long sequence cut into 20 pieces merges in 5 rounds
+    for (int j0 = P.jf; j0 <= P.jl; j0 += 4) {
+      float mp[4], lp[4], op[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int jj = j0 + u <= P.jl ? j0 + u : P.jl;   // past the end: the last piece again, weight 0
+        // workgroup jj's piece of this sequence: its first piece if its range starts inside the
+        // sequence, else its last one
+        const int64_t a_jj = (int64_t)jj * P.n_tot / P.gk;
+        const float* sl = P.slots + (size_t)(2 * jj + (a_jj >= P.pre ? 0 : 1)) * pa_slot_floats<HEAD_SIZE>();
+        mp[u] = __hip_atomic_load(sl + 16 * HEAD_SIZE + qh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lp[u] = __hip_atomic_load(sl + 16 * HEAD_SIZE + 16 + qh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          op[u][j] = __hip_atomic_load(sl + qh * HEAD_SIZE + d0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j0 + u > P.jl) break;
+        const float mn = fmaxf(M, mp[u]);
+        const float fo = fast_exp2(M - mn), fp = fast_exp2(mp[u] - mn);
+        L = L * fo + lp[u] * fp;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = acc[j] * fo + op[u][j] * fp;
+        M = mn;
+      }
+    }
+    const float inv = __fdividef(1.f, L + 1e-6f) * vscale;
+    uint4 pk;
+    pk.x = Mma<scalar_t>::pack2(acc[0] * inv, acc[1] * inv);
+    pk.y = Mma<scalar_t>::pack2(acc[2] * inv, acc[3] * inv);
+    pk.z = Mma<scalar_t>::pack2(acc[4] * inv, acc[5] * inv);
+    pk.w = Mma<scalar_t>::pack2(acc[6] * inv, acc[7] * inv);
+    *reinterpret_cast<uint4*>(out + ((int64_t)qrow * num_heads + head0 + qh) * dr + d0) = pk;
+  }
+}
+
+template <typename scalar_t, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int NW, int VARIANT, bool PAD, bool BAL>
+__global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
+    scalar_t* __restrict__ out, float* __restrict__ exp_sums, float* __restrict__ max_logits,
+    const scalar_t* __restrict__ q, const uint8_t* __restrict__ k_cache,
+    const uint8_t* __restrict__ v_cache, int num_heads, int num_kv_heads, float scale,
+    const int* __restrict__ block_tables, const int* __restrict__ seq_lens,
+    const int* __restrict__ query_start_loc, int max_num_blocks_per_seq,
+    const float* __restrict__ alibi_slopes, int64_t q_stride, int64_t kv_block_bytes,
+    int64_t kv_head_bytes, const float* __restrict__ k_scale_p,
+    const float* __restrict__ v_scale_p, int partition_size, int max_parts, int gqa_chunks,
+    int slot_stride_arg, int dr_arg, float* __restrict__ bal_ws, unsigned* __restrict__ bal_ctr,
+    int num_seqs) {
+  VA_STAMP_DECL;
+  VA_STAMP(0);
+  // (the pointers stay __restrict__ kernel parameters: as members of a by-value struct they lose
+  // the no-alias guarantee, the block-table loads turn from scalar into vector loads, and every
+  // K / V issue then waits behind the loads in flight)
+  const PaK<scalar_t> A{out, exp_sums, max_logits, q, k_cache, v_cache, num_heads, num_kv_heads, scale,
+                        block_tables, seq_lens, query_start_loc, max_num_blocks_per_seq, alibi_slopes,
+                        q_stride, kv_block_bytes, kv_head_bytes, k_scale_p, v_scale_p, partition_size,
+                        max_parts, gqa_chunks, slot_stride_arg, dr_arg, bal_ws, bal_ctr, num_seqs};
+  constexpr int STEP_TOK = (FP8 ? 4 : 2) * 16;
+  constexpr int P_BYTES = 16 * kPRowBytes;
+  constexpr int MERGE_BYTES = NW * HEAD_SIZE * 16 * 4 + NW * 16 * 8;
+  constexpr int LDS_BYTES = (NW * P_BYTES > MERGE_BYTES) ? NW * P_BYTES : MERGE_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES + 16];   // + the "last ticket" flag
+  const int lane = threadIdx.x & 63;
+
+  // logical id = ((seq * num_kv_heads + kvh) * gqa_chunks + chunk), blockIdx.y = partition
+  int wg = blockIdx.x;
+  int slot_stride = A.slot_stride;
+  // Large launches: consecutive hardware ids go to different XCDs (id % 8); remapped so that the
+  // kv heads of a sequence -- adjacent pages of the same blocks -- stream through one XCD's L2
+  // (256 sequences x 8 kv heads x 4096 fp8: 330.6 -> 324.6 us; nothing at 512 workgroups)
+  if (slot_stride < 0) {
+    const int nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
+    wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  const int chunk = wg % A.gqa_chunks;
+  const int kvh = (wg / A.gqa_chunks) % A.num_kv_heads;
+  const int groups = A.gqa_chunks * A.num_kv_heads;
+  PaPiece P;
+  if constexpr (!BAL) {
+    const int seq = wg / groups;
+    const int part = blockIdx.y;
+    P.seq = seq;
+    P.qrow = seq;
+    if (A.query_start_loc) {
+      if (A.query_start_loc[seq + 1] - A.query_start_loc[seq] != 1) return;
+      P.qrow = A.query_start_loc[seq];
+    }
+    P.seq_len = A.seq_lens[seq];
+    const bool partitioned = A.partition_size > 0;
+    P.start_tok = partitioned ? part * A.partition_size : 0;
+    if (partitioned && P.start_tok >= P.seq_len) return;
+    P.end_tok = partitioned ? min(P.start_tok + A.partition_size, P.seq_len) : P.seq_len;
+    P.mode = partitioned ? 1 : 0;
+    P.part = part;
+    PaK<scalar_t> B = A;
+    B.slot_stride = slot_stride < 0 ? -slot_stride : slot_stride;
+    pa_piece<scalar_t, FP8, HEAD_SIZE, BLOCK_SIZE, NW, VARIANT, PAD>(B, lds, P, kvh, chunk VA_STAMP_ARG);
+  } else {
+    // ---- balanced launch (v1, no partitions): the steps of all sequences, concatenated, are
+    // cut into gk equal ranges per (kv head, q-head chunk); workgroup j takes range j, which
+    // covers the end of one sequence, whole sequences, and the start of another.  Every
+    // workgroup derives the same cut from seq_lens by itself (one wave-wide scan): no queue, no
+    // atomics unless a sequence is shared.  A sequence of length 0 counts one (empty) step so
+    // that somebody writes its zero output.
+    const int S = A.num_seqs;
+    auto nst = [&](int len) { const int n = (len + STEP_TOK - 1) / STEP_TOK; return n > 0 ? n : 1; };
+    int n_tot = 0;
+    for (int i = lane; i < S; i += 64) n_tot += nst(A.seq_lens[i]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) n_tot += __shfl_xor(n_tot, m, 64);
+    n_tot = __builtin_amdgcn_readfirstlane(n_tot);
+    const int gk_launch = gridDim.x / groups;
+    const int gk = gk_launch < n_tot ? gk_launch : n_tot;   // never an empty range between two pieces
+    const int j = wg / groups;
+    if (j >= gk) return;
+    const int ra = (int)((int64_t)j * n_tot / gk), rb = (int)((int64_t)(j + 1) * n_tot / gk);
+    // the sequence that holds step ra, and the number of steps in front of it
+    int s = 0, pre = 0;
+    {
+      int base = 0;
+      for (int i0 = 0; i0 < S; i0 += 64) {
+        const int n = (i0 + lane < S) ? nst(A.seq_lens[i0 + lane]) : 0;
+        int incl = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int t = __shfl_up(incl, d, 64);
+          if (lane >= d) incl += t;
+        }
+        const int excl = incl - n;
+        const unsigned long long mask = __ballot(base + excl <= ra && ra < base + incl);
+        if (mask) {
+          const int l = __ffsll((long long)mask) - 1;
+          s = i0 + l;
+          pre = base + __shfl(excl, l, 64);
+          break;
+        }
+        base += __shfl(incl, 63, 64);
+      }
+      s = __builtin_amdgcn_readfirstlane(s);
+      pre = __builtin_amdgcn_readfirstlane(pre);
+    }
+    const float* slots = A.bal_ws + (size_t)(kvh * A.gqa_chunks + chunk) * gk_launch * 2 * pa_slot_floats<HEAD_SIZE>();
+    int cur = ra;
+    while (cur < rb) {
+      const int len = A.seq_lens[s];
+      const int n_s = nst(len);
+      const int ls0 = cur - pre, ls1 = min(rb - pre, n_s);
+      P.seq = s;
+      P.qrow = s;
+      P.seq_len = len;
+      P.start_tok = ls0 * STEP_TOK;
+      P.end_tok = min(ls1 * STEP_TOK, len);
+      P.part = 0;
+      if (ls0 == 0 && ls1 == n_s) {
+        P.mode = 0;
+      } else {
+        P.mode = 2;
+        P.jf = (int)((((int64_t)pre + 1) * gk - 1) / n_tot);
+        P.jl = (int)((((int64_t)pre + n_s) * gk - 1) / n_tot);
+        P.pre = pre;
+        P.n_tot = n_tot;
+        P.gk = gk;
+        P.slots = slots;
+        P.slot = const_cast<float*>(slots) + (size_t)(2 * j + (cur == ra ? 0 : 1)) * pa_slot_floats<HEAD_SIZE>();
+        P.ticket = A.bal_ctr + ((size_t)s * A.num_kv_heads + kvh) * A.gqa_chunks + chunk;
+      }
+      pa_piece<scalar_t, FP8, HEAD_SIZE, BLOCK_SIZE, NW, VARIANT, PAD>(A, lds, P, kvh, chunk VA_STAMP_ARG);
+      __syncthreads();   // the next piece's P tiles overlay the merge buffers this one still reads
+      cur = pre + ls1;
+      pre += n_s;
+      ++s;
+    }
   }
   VA_STAMP_FLUSH();
 }
@@ -479,6 +698,16 @@ void set_pa_sp(int v) { g_pa_sp = v; }
 static int g_pa_group = 0;
 void set_pa_group(int v) { g_pa_group = v; }
 
+#define PA_ARGS(A)                                                                                 \
+  (A).out, (A).exp_sums, (A).max_logits, (A).q, (A).k_cache, (A).v_cache, (A).num_heads,           \
+      (A).num_kv_heads, (A).scale, (A).block_tables, (A).seq_lens, (A).query_start_loc,            \
+      (A).max_num_blocks_per_seq, (A).alibi_slopes, (A).q_stride, (A).kv_block_bytes,              \
+      (A).kv_head_bytes, (A).k_scale_p, (A).v_scale_p, (A).partition_size, (A).max_parts,          \
+      (A).gqa_chunks, (A).slot_stride, (A).dr_arg, (A).bal_ws, (A).bal_ctr, (A).num_seqs
+
+static int g_pa_balance = 0;   // tuning "pa_balance": 1 = balanced v1 launches whenever possible, else never
+void set_pa_balance(int v) { g_pa_balance = v; }
+
 template <typename scalar_t, bool FP8, int HS, int BS, int VARIANT, bool PAD>
 static int launch_mfma_v(const PagedAttnParams& p) {
   constexpr int NW = 4;
@@ -492,15 +721,48 @@ static int launch_mfma_v(const PagedAttnParams& p) {
   void* out = part ? p.tmp_out : p.out;
   // "pa_group": 0 = heuristic, 1 = always, 2 = never
   const bool group = g_pa_group == 1 || (g_pa_group == 0 && p.num_kv_heads >= 2 && grid.x >= 1024);
-#define PA_ARGS                                                                                  \
-  (scalar_t*)out, p.exp_sums, p.max_logits, (const scalar_t*)p.query,                           \
-      (const uint8_t*)p.key_cache, (const uint8_t*)p.value_cache, p.num_heads, p.num_kv_heads,  \
-      p.scale, p.block_tables, p.seq_lens, p.query_start_loc, p.max_num_blocks_per_seq,         \
-      p.alibi_slopes, p.q_stride, p.kv_block_stride * es, p.kv_head_stride * es, p.k_scale,     \
-      p.v_scale, p.partition_size * sp, p.max_num_partitions, chunks, (group ? -sp : sp), p.head_size
-  hipLaunchKernelGGL((pa_mfma_kernel<scalar_t, FP8, HS, BS, NW, VARIANT, PAD>), grid, dim3(NW * 64), 0,
-                     p.stream, PA_ARGS);
-#undef PA_ARGS
+  PaK<scalar_t> A;
+  A.out = (scalar_t*)out; A.exp_sums = p.exp_sums; A.max_logits = p.max_logits;
+  A.q = (const scalar_t*)p.query; A.k_cache = (const uint8_t*)p.key_cache;
+  A.v_cache = (const uint8_t*)p.value_cache; A.num_heads = p.num_heads;
+  A.num_kv_heads = p.num_kv_heads; A.scale = p.scale; A.block_tables = p.block_tables;
+  A.seq_lens = p.seq_lens; A.query_start_loc = p.query_start_loc;
+  A.max_num_blocks_per_seq = p.max_num_blocks_per_seq; A.alibi_slopes = p.alibi_slopes;
+  A.q_stride = p.q_stride; A.kv_block_bytes = p.kv_block_stride * es;
+  A.kv_head_bytes = p.kv_head_stride * es; A.k_scale_p = p.k_scale; A.v_scale_p = p.v_scale;
+  A.partition_size = p.partition_size * sp; A.max_parts = p.max_num_partitions;
+  A.gqa_chunks = chunks; A.slot_stride = group ? -sp : sp; A.dr_arg = p.head_size;
+  A.bal_ws = nullptr; A.bal_ctr = nullptr; A.num_seqs = p.num_seqs;
+
+  // Balanced v1 launch (opt-in, "pa_balance" = 1): paged_attention_v1 has no scratch arguments,
+  // so with one workgroup per (sequence, kv head) a skewed batch waits for its longest sequence.
+  // With a registered workspace (vllm_amd_set_workspace) the concatenated steps of all sequences
+  // are cut into equal ranges, two workgroups per CU; a sequence shared by several workgroups is
+  // merged through the workspace by whoever finishes last (kernel above).  Measured
+  // (profiles/r02_decode_balanced.txt): the merge of a shared sequence costs its last finisher
+  // 5-7 us at the end of the launch, so it pays on skewed batches (one long sequence among many
+  // short ones) and loses 2-7 us on uniform and mildly ragged ones -- the host cannot tell the
+  // two apart (seq_lens live on the device), hence not the default.
+  if (!part && !p.query_start_loc && g_pa_balance == 1) {
+    const int groups = p.num_kv_heads * chunks;
+    const int64_t steps_ub = (int64_t)p.num_seqs * ceil_div(p.max_seq_len > 0 ? p.max_seq_len : 1, FP8 ? 64 : 32);
+    int gk = 512 / groups;
+    if (gk > steps_ub) gk = (int)steps_ub;
+    WsSlot slot;
+    const size_t need = (size_t)groups * (gk > 0 ? gk : 1) * 2 * pa_slot_floats<HS>() * sizeof(float);
+    if (gk >= 1 && (int64_t)p.num_seqs * groups <= (int64_t)WS_CTR_PA_WORDS &&
+        workspace_slot(p.stream, &slot) && need <= slot.data_bytes) {
+      A.bal_ws = (float*)slot.data;
+      A.bal_ctr = slot.ctr_pa;
+      A.slot_stride = 1;
+      hipLaunchKernelGGL((pa_mfma_kernel<scalar_t, FP8, HS, BS, NW, VARIANT, PAD, true>),
+                         dim3((unsigned)(groups * gk)), dim3(NW * 64), 0, p.stream, PA_ARGS(A));
+      VA_LAUNCH_CHECK("paged_attention mfma launch (balanced)");
+      return VLLM_AMD_OK;
+    }
+  }
+  hipLaunchKernelGGL((pa_mfma_kernel<scalar_t, FP8, HS, BS, NW, VARIANT, PAD, false>), grid, dim3(NW * 64), 0,
+                     p.stream, PA_ARGS(A));
   VA_LAUNCH_CHECK("paged_attention mfma launch");
   if (part) return paged_attention_reduce(p);
   return VLLM_AMD_OK;

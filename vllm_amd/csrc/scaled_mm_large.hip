@@ -417,44 +417,16 @@ struct GldsArgs {
   int ws_mode;   // 0 = registered workspace (or unsplit), 1 = the static scratch below (or an error)
 };
 
-// Split-K workspace: CALLER-OWNED device memory registered per device with
-// vllm_amd_scaled_mm_set_workspace() (below) -- nothing is allocated in an op call; without a
-// registered workspace every launch runs unsplit.  Layout: SPLIT_SLOTS ticket-counter areas of
-// SPLIT_CTR_TILES words, then SPLIT_SLOTS equal areas of fp32 partials.  A slot belongs to ONE
-// stream (assigned at that stream's first split launch, kept until the workspace is replaced):
-// launches of one stream are ordered, so they may share a slot; streams never share one.  A
-// stream that finds no free slot, a launch under stream capture (the graph could replay on any
-// stream, beside eager launches), and a launch that needs more than a slot all run unsplit.
-// Counters reset themselves (kernel above) and are zeroed when the workspace is registered.
-constexpr int SPLIT_SLOTS = 4;
-constexpr int SPLIT_CTR_TILES = 4096;
-constexpr size_t SPLIT_CTR_BYTES = (size_t)SPLIT_SLOTS * SPLIT_CTR_TILES * sizeof(unsigned);
-struct SplitWs { char* base; size_t slot_bytes; hipStream_t streams[SPLIT_SLOTS]; int nstreams; };
-static SplitWs g_split_ws[64];
-static std::mutex g_split_mu;
+// Split-K workspace: one stream slot of the caller-registered workspace (common.cuh,
+// vllm_amd_set_workspace); no slot (none registered, stream capture, a fifth stream) or a launch
+// that needs more than the slot holds -> unsplit.  Counters reset themselves (kernel above).
+static std::mutex g_split_mu;   // guards g_mm_scratch_ptr below
 
 static bool split_workspace(hipStream_t st, size_t bytes, int tiles, float** ws, unsigned** ctr) {
-  int dev = 0;
-  if (tiles > SPLIT_CTR_TILES) return false;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  std::lock_guard<std::mutex> lk(g_split_mu);
-  SplitWs& w = g_split_ws[dev];
-  if (!w.base || bytes > w.slot_bytes) return false;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-    (void)hipGetLastError();
-    return false;
-  }
-  int slot = -1;
-  for (int i = 0; i < w.nstreams; ++i)
-    if (w.streams[i] == st) slot = i;
-  if (slot < 0) {
-    if (w.nstreams == SPLIT_SLOTS) return false;
-    slot = w.nstreams++;
-    w.streams[slot] = st;
-  }
-  *ctr = (unsigned*)w.base + (size_t)slot * SPLIT_CTR_TILES;
-  *ws = (float*)(w.base + SPLIT_CTR_BYTES + (size_t)slot * w.slot_bytes);
+  WsSlot slot;
+  if (tiles > (int)WS_CTR_MM_WORDS || !workspace_slot(st, &slot) || bytes > slot.data_bytes) return false;
+  *ctr = slot.ctr_mm;
+  *ws = (float*)slot.data;
   return true;
 }
 
@@ -571,35 +543,3 @@ int launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
 }
 
 }  // namespace va
-
-// Registers (ws != NULL) or removes (ws == NULL) the calling device's split-K workspace of
-// vllm_amd_scaled_mm: `bytes` of caller-owned device memory, 256-byte aligned, that must stay
-// valid until it is replaced or removed.  The ticket counters at its start are zeroed on `stream`
-// (asynchronously: order the first scaled_mm call behind it).  Replacing a workspace while
-// split launches are in flight is the caller's race.
-extern "C" int vllm_amd_scaled_mm_set_workspace(void* ws, int64_t bytes, void* stream) {
-  using namespace va;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
-    set_error("scaled_mm_set_workspace: no current device");
-    return VLLM_AMD_EHIP;
-  }
-  if (ws == nullptr) {
-    std::lock_guard<std::mutex> lk(g_split_mu);
-    g_split_ws[dev] = SplitWs{};
-    return VLLM_AMD_OK;
-  }
-  VA_REQUIRE((((uintptr_t)ws) & 255) == 0, VLLM_AMD_EINVAL,
-             "scaled_mm_set_workspace: the workspace must be 256-byte aligned");
-  VA_REQUIRE(bytes >= (int64_t)(SPLIT_CTR_BYTES + SPLIT_SLOTS * 256), VLLM_AMD_EINVAL,
-             "scaled_mm_set_workspace: workspace of %lld bytes is too small (minimum %lld)",
-             (long long)bytes, (long long)(SPLIT_CTR_BYTES + SPLIT_SLOTS * 256));
-  hipError_t e = hipMemsetAsync(ws, 0, SPLIT_CTR_BYTES, (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "scaled_mm_set_workspace");
-  std::lock_guard<std::mutex> lk(g_split_mu);
-  SplitWs w{};
-  w.base = (char*)ws;
-  w.slot_bytes = (((size_t)bytes - SPLIT_CTR_BYTES) / SPLIT_SLOTS) & ~(size_t)255;
-  g_split_ws[dev] = w;
-  return VLLM_AMD_OK;
-}
