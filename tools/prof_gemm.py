@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_amd import _custom_ops as ops
 
 dev = torch.device("cuda", 0)
-for (M, K, N) in ((4096, 4096, 4096), (4096, 14336, 4096), (256, 4096, 6144), (64, 4096, 6144), (1, 4096, 4096)):
+for (M, K, N) in ((4096, 4096, 4096), (4096, 14336, 4096), (4096, 4096, 28672), (256, 4096, 6144), (64, 4096, 6144), (1, 4096, 4096)):
     w = torch.randn((N, K), device=dev, dtype=torch.bfloat16)
     wq, ws = ops.scaled_fp8_quant(w, use_per_token_if_dynamic=True)
     a = torch.randn((M, K), device=dev, dtype=torch.bfloat16)

@@ -40,6 +40,19 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 constexpr int LBK = 128;
 
+// measurement builds only (tools/): -DVA_MM_ABLATE=1 no LDS-DMA refill inside the K loop,
+// 2 no MFMA (fragments kept alive), 3 no fragment reads (MFMA on whatever the registers hold).
+// Results are garbage; the time says what each part of the loop costs.
+#ifndef VA_MM_ABLATE
+#define VA_MM_ABLATE 0
+#endif
+// -DVA_PROBES: shader-clock (s_memtime) and 100 MHz (s_memrealtime) stamps around the K loop of
+// every workgroup -> in-kernel clock and cycles per K block (tools/mm_stamps.py)
+#ifdef VA_PROBES
+__device__ unsigned long long g_mm_stamps[4096 * 4];
+__device__ unsigned long long g_mm_stamps_end[4096];
+#endif
+
 __device__ __forceinline__ int lswz(int row) {
   return ((row >> 1) & 1) | (((row >> 2) & 1) << 2);
 }
@@ -47,7 +60,11 @@ __device__ __forceinline__ int lswz(int row) {
 template <int OFF>
 __device__ __forceinline__ i32x4 lds_read16(uint32_t addr) {
   i32x4 v;
+#if VA_MM_ABLATE == 3
+  asm volatile("; no read %0 %1" : "=v"(v) : "v"(addr));
+#else
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+#endif
   return v;
 }
 
@@ -86,6 +103,15 @@ __device__ __forceinline__ void wait_wa(i32x4& w0, i32x4& w1, i32x4& a0, i32x4& 
   asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(w0), "+v"(w1), "+v"(a0), "+v"(a1) : [n] "n"(LATER));
 }
 
+__device__ __forceinline__ f32x4 mm_mfma(i32x8 w, i32x8 a, f32x4 acc) {
+#if VA_MM_ABLATE == 2
+  asm volatile("" ::"v"(w), "v"(a));
+  return acc;
+#else
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, a, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#endif
+}
+
 __device__ __forceinline__ i32x8 cat8(i32x4 lo, i32x4 hi) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
@@ -97,9 +123,21 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
     const float* __restrict__ a_scales, const float* __restrict__ b_scales,
     const out_t* __restrict__ bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
     int a_scale_numel, int b_scale_numel, float* ws, unsigned* ctr, int S) {
+  const bool nt_store = (int64_t)M * N * (int64_t)sizeof(out_t) >= ((int64_t)128 << 20);
   constexpr int NW = WM * WN;
+#ifdef VA_MM_LATE_FILL   // measurement builds: see the K loop
+  constexpr bool LATE_FILL = NW == 8 && NST == 2 && !SPLITK;
+#else
+  constexpr bool LATE_FILL = false;
+#endif
+
   constexpr int A_BYTES = BM * LBK, W_BYTES = BN * LBK, STAGE = A_BYTES + W_BYTES;
   constexpr int MT = BM / WM / 16, NT = BN / WN / 16;   // MFMA tiles per wave
+#ifndef VA_MM_PF
+#define VA_MM_PF 1
+#endif
+  // fragment prefetch distance of the one-block-per-barrier kernels, in m-steps
+  constexpr int PF = (KB == 1 && MT >= 4) ? VA_MM_PF : 1;
   constexpr int RPR = 8 * NW;                            // rows staged per glds round
   constexpr int A_ROUNDS = BM / RPR, W_ROUNDS = BN / RPR;
   static_assert(BM % RPR == 0 && BN % RPR == 0, "tile rows must fill whole glds rounds");
@@ -174,6 +212,9 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef VA_PROBES
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // fragment read addresses: the swizzle depends on c16 only, so tile t is an immediate
   // offset t * 16 * LBK from one per-lane base per 16-byte half (j) and operand
@@ -210,8 +251,12 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
     // own DMA of group g has landed (in the steady state everything but the NST-2 younger
     // groups; near the end fewer are in flight, so drain); then everybody's has, and
     // everybody is done reading the buffer that is restaged next
+#if VA_MM_ABLATE == 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     if (g + NST - 1 <= ng) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * KB * LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
 
     const uint32_t so = cur * (KB * STAGE);
@@ -223,12 +268,57 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
     // exactly the reads issued after the ones it needs.  A block starts with the reads
     // W0, A0, W1 .. W(NT-1): its first MFMA waits for 4 reads, not for all of them.
     static_assert(MT >= 2, "the wait counts below assume a block has >= 2 m-steps");
+    if constexpr (PF == 2) {
+      // one block per barrier, activation fragments requested TWO m-steps ahead (three register
+      // sets): under the LDS-DMA refill an LDS read takes longer than one m-step of MFMAs
+      i32x4 wl[NT], wh[NT], al[3], ah[3];
+      i32x8 wf[NT];
+      block_start<0>(wa0, wa1, aa0, aa1, wl, wh, al[0], ah[0]);
+      lds_read_frag<0, 1>(aa0, aa1, al[1], ah[1]);
+#if VA_MM_ABLATE != 1
+      if (g + NST - 1 < ng) group_load(nxt, g + NST - 1);
+#endif
+      nxt = cur;
+      cur = cur + 1 == NST ? 0 : cur + 1;
+      static_for<MT>([&](auto ic) {
+        constexpr int mt = decltype(ic)::value;
+        if constexpr (mt + 2 < MT) lds_read_frag<0, mt + 2>(aa0, aa1, al[(mt + 2) % 3], ah[(mt + 2) % 3]);
+        constexpr int pend = 2 * (MT - 1 - mt < 2 ? MT - 1 - mt : 2);   // younger A reads
+        if constexpr (mt == 0) {
+          wait_wa<pend + 2 * (NT - 1)>(wl[0], wh[0], al[0], ah[0]);
+          const i32x8 af = cat8(al[0], ah[0]);
+          wf[0] = cat8(wl[0], wh[0]);
+          acc[0][0] = mm_mfma(wf[0], af, acc[0][0]);
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<NT - 1>([&](auto jc) {
+            constexpr int nt = decltype(jc)::value + 1;
+            wait_frag<pend + 2 * (NT - 1 - nt)>(wl[nt], wh[nt]);
+            wf[nt] = cat8(wl[nt], wh[nt]);
+            acc[nt][0] = mm_mfma(wf[nt], af, acc[nt][0]);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        } else {
+          wait_frag<pend>(al[mt % 3], ah[mt % 3]);
+          const i32x8 af = cat8(al[mt % 3], ah[mt % 3]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = mm_mfma(wf[nt], af, acc[nt][mt]);
+        }
+      });
+      continue;
+    }
     i32x4 wl[2][NT], wh[2][NT];   // weight fragments of block kb in [kb & 1]
     i32x4 al[2], ah[2];           // activation fragment of step s in [s & 1]
     i32x8 wf[NT];
     block_start<0>(wa0, wa1, aa0, aa1, wl[0], wh[0], al[0], ah[0]);
-    // the refill is issued behind the first fragment reads: they are what the MFMAs wait for
-    if (g + NST - 1 < ng) group_load(nxt, g + NST - 1);
+    // The refill is issued behind the first fragment reads (they are what the MFMAs wait for).
+    // (-DVA_MM_LATE_FILL, measurement builds: the second half of an 8-wave workgroup refills
+    // behind its MFMAs instead, so that one wave of every SIMD computes while the other feeds the
+    // DMA queue -- no gain, profiles/r02_gemm_ablation.txt.)
+    const int fill = nxt;
+    const bool late_fill = LATE_FILL && wave >= NW / 2;
+#if VA_MM_ABLATE != 1
+    if (!late_fill && g + NST - 1 < ng) group_load(fill, g + NST - 1);
+#endif
     nxt = cur;
     cur = cur + 1 == NST ? 0 : cur + 1;
     static_for<KB * MT>([&](auto ic) {
@@ -247,8 +337,7 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
         wait_wa<later + 2 * (NT - 1)>(wl[kb & 1][0], wh[kb & 1][0], al[s & 1], ah[s & 1]);
         const i32x8 af = cat8(al[s & 1], ah[s & 1]);
         wf[0] = cat8(wl[kb & 1][0], wh[kb & 1][0]);
-        acc[0][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-            wf[0], af, acc[0][mt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        acc[0][mt] = mm_mfma(wf[0], af, acc[0][mt]);
         // keep each MFMA above the next wait (the scheduler would sink all of them below
         // the last one and the early start would be lost)
         __builtin_amdgcn_sched_barrier(0);
@@ -256,8 +345,7 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
           constexpr int nt = decltype(jc)::value + 1;
           wait_frag<later + 2 * (NT - 1 - nt)>(wl[kb & 1][nt], wh[kb & 1][nt]);
           wf[nt] = cat8(wl[kb & 1][nt], wh[kb & 1][nt]);
-          acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-              wf[nt], af, acc[nt][mt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          acc[nt][mt] = mm_mfma(wf[nt], af, acc[nt][mt]);
           __builtin_amdgcn_sched_barrier(0);
         });
       } else {
@@ -265,11 +353,25 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
         const i32x8 af = cat8(al[s & 1], ah[s & 1]);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-              wf[nt], af, acc[nt][mt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          acc[nt][mt] = mm_mfma(wf[nt], af, acc[nt][mt]);
       }
     });
+#if VA_MM_ABLATE != 1
+    if constexpr (LATE_FILL) {
+      __builtin_amdgcn_sched_barrier(0);   // keep the refill behind the MFMAs
+      if (late_fill && g + NST - 1 < ng) group_load(fill, g + NST - 1);
+    }
+#endif
   }
+#ifdef VA_PROBES
+  {
+    const unsigned long long st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && blockIdx.x < 4096) {
+      g_mm_stamps[blockIdx.x * 4 + 0] = st_c0; g_mm_stamps[blockIdx.x * 4 + 1] = st_r0;
+      g_mm_stamps[blockIdx.x * 4 + 2] = st_c1; g_mm_stamps[blockIdx.x * 4 + 3] = st_r1;
+    }
+  }
+#endif
 
   if constexpr (SPLITK) {
     // Split-K fix-up without a second kernel: every slice parks its fp32 accumulators in
@@ -384,8 +486,20 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
       const int ch = lane % CPR;                 // 16-byte chunk = 8 outputs
       const uint4 v = *reinterpret_cast<const uint4*>(lds + row * ROWB + ((ch ^ (row & SWZ)) << 4));
       const int m = m0 + row, n = n0 + 8 * ch;
-      if (m < M && n < N) *reinterpret_cast<uint4*>(out + (int64_t)m * ldc + n) = v;
+      if (m < M && n < N) {
+        // an output beyond ~half of the 256 MiB Infinity Cache would push the operand panels the
+        // other tiles still need out of it: streamed past it instead (4096 x 28672: 415 -> 395 us;
+        // smaller outputs measured 0 .. 3 % slower that way)
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        u32x4* dst = reinterpret_cast<u32x4*>(out + (int64_t)m * ldc + n);
+        if (nt_store) __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, dst);
+        else *dst = (u32x4){v.x, v.y, v.z, v.w};
+      }
     }
+#ifdef VA_PROBES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's stores have left
+    if (tid == 0 && blockIdx.x < 4096) g_mm_stamps_end[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     return;
   }
 #pragma unroll
@@ -543,3 +657,12 @@ int launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
 }
 
 }  // namespace va
+
+#ifdef VA_PROBES
+extern "C" int vllm_amd_probe_mm_stamps(unsigned long long* dst, int nwg) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(va::g_mm_stamps), (size_t)nwg * 4 * 8) == hipSuccess ? 0 : -3;
+}
+extern "C" int vllm_amd_probe_mm_stamps_end(unsigned long long* dst, int nwg) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(va::g_mm_stamps_end), (size_t)nwg * 8) == hipSuccess ? 0 : -3;
+}
+#endif
