@@ -127,9 +127,14 @@ def test_validation_errors_without_launch():
 def test_torch_layer_rejects_cpu_tensors_and_bad_strings():
     from vllm_amd import _custom_ops as ops, _torch_ops
     x = torch.zeros((2, 16), dtype=torch.bfloat16)
-    with pytest.raises(RuntimeError, match="device tensors"):
+    # CPU tensors: the operators exist for the CUDA(=HIP) key only, the dispatcher refuses them
+    # (NotImplementedError, a RuntimeError) exactly as it does for the reference's C++ ops
+    with pytest.raises(RuntimeError, match="'CPU' backend"):
         _torch_ops.static_scaled_fp8_quant(torch.zeros((2, 16), dtype=torch.float8_e4m3fn), x,
                                            torch.ones(1))
+    # the implementations live in the C++ shim, not in Python
+    assert "torch_shim.cpp" in torch._C._dispatch_dump("_C::cutlass_scaled_mm")
+    assert "torch_shim.cpp" in torch._C._dispatch_dump("_C_cache_ops::swap_blocks")
     with pytest.raises(RuntimeError, match="Unsupported data type of kv cache: fp8_e5m2"):
         _torch_ops._kv("fp8_e5m2")
     assert ops.FP8_DTYPE == torch.float8_e4m3fn

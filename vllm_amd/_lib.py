@@ -71,7 +71,9 @@ def _load() -> C.CDLL:
             f"{LIB_PATH} not found: the HIP library is not built. Run "
             "`make -C vllm_amd/csrc` (hipcc, gfx950). vllm_amd has no CPU or "
             "eager fallback.")
-    lib = C.CDLL(LIB_PATH)
+    # RTLD_GLOBAL: the torch shim (libvllm_amd_torch.so) binds the vllm_amd_* symbols of THIS
+    # library, also when VLLM_AMD_LIB names another build of it
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
         fn.argtypes = argtypes
