@@ -389,6 +389,9 @@ int vllm_amd_unified_attention(
 /*                 take 2 or 4 K blocks per barrier; scaled_mm_large.hip),      */
 /*                 11 = weight-streaming kernel (M <= 32 only),                 */
 /*                 12, 13 = 32x128 tile (1 / 2 K blocks per barrier)            */
+/*                 14 = 256x256 tile on 4 waves (accumulators in AGPRs),        */
+/*                 15 = 256x256 tile, ring of five half stages (measured, not   */
+/*                 used by the heuristic: profiles/r02_gemm_ablation.txt)       */
 /*   "pf_rows":    query rows per workgroup of the prefill kernels (0 = default,    */
 /*                 64 / 128); 1 = unified_attention without GQA packing          */
 /*   "uni_decode": 0 = unified_attention never uses its decode kernel (1 =     */

@@ -77,7 +77,10 @@ __device__ __forceinline__ void lds_read_frag(uint32_t a0, uint32_t a1, i32x4& l
   hi = lds_read16<BASE + T * 16 * LBK>(a1);
 }
 
-// first reads of a K block, in the order its MFMAs consume them: W0, A0, W1 .. W(NT-1)
+// first reads of a K block, in the order its MFMAs consume them: W0, A0, W1 .. W(WA-1), where
+// WA = min(NT, 4) weight fragments are requested up front (lgkmcnt has 4 bits: at most 15 reads
+// can be counted); the first m-step requests W(nt + WA) in front of its MFMA nt.
+template <int NT> constexpr int w_ahead() { return NT < 4 ? NT : 4; }
 template <int BASE, int NT>
 __device__ __forceinline__ void block_start(uint32_t w0, uint32_t w1, uint32_t a0, uint32_t a1,
                                             i32x4 (&wl)[NT], i32x4 (&wh)[NT], i32x4& al, i32x4& ah) {
@@ -88,6 +91,10 @@ __device__ __forceinline__ void block_start(uint32_t w0, uint32_t w1, uint32_t a
     lds_read_frag<BASE, 2>(w0, w1, wl[2], wh[2]);
     lds_read_frag<BASE, 3>(w0, w1, wl[3], wh[3]);
   }
+}
+// reads of W fragments younger than W(nt) at the moment MFMA nt of the first m-step waits
+template <int NT> constexpr int w_younger(int nt) {
+  return (nt + w_ahead<NT>() < NT - 1 ? nt + w_ahead<NT>() : NT - 1) - nt;
 }
 
 // s_waitcnt lgkmcnt(LATER) = "all LDS reads but the LATER youngest have returned".  The
@@ -141,12 +148,20 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
   constexpr int RPR = 8 * NW;                            // rows staged per glds round
   constexpr int A_ROUNDS = BM / RPR, W_ROUNDS = BN / RPR;
   static_assert(BM % RPR == 0 && BN % RPR == 0, "tile rows must fill whole glds rounds");
-  static_assert(NT == 1 || NT == 2 || NT == 4, "");
+  static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8, "");
+  constexpr int WA = w_ahead<NT>();
   static_assert(MT >= 1 && MT <= 8, "");
-  static_assert(NST >= 2 && NST * KB * STAGE <= 160 * 1024, "");
+  // NST == 5 (square tiles, KB = 1): not five stages but a ring of five HALF stages -- the A and
+  // the W image of a K block are staged separately, in the order A0 W0 A1 W1 .., so that one half
+  // stage is always in flight across a barrier (two whole stages leave the fill path idle for a
+  // load latency after every barrier; three do not fit the 160 KB).  See the R5 loop below.
+  constexpr bool R5 = NST == 5;
+  static_assert(!R5 || (KB == 1 && A_BYTES == W_BYTES && !SPLITK), "");
+  constexpr int LDS_TOTAL = R5 ? 5 * A_BYTES : NST * KB * STAGE;
+  static_assert(NST >= 2 && LDS_TOTAL <= 160 * 1024, "");
   constexpr int LOADS = A_ROUNDS + W_ROUNDS;           // glds per lane and stage
-  static_assert((NST - 2) * KB * LOADS <= 63, "vmcnt is 6 bits");
-  __shared__ __attribute__((aligned(16))) uint8_t lds[NST * KB * STAGE];
+  static_assert(R5 || (NST - 2) * KB * LOADS <= 63, "vmcnt is 6 bits");
+  __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TOTAL];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -243,11 +258,78 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) stage_load(buf * KB + kb, (g * KB + kb) * LBK);
   };
+  if constexpr (R5) {
+    auto load_a = [&](int slot, int k0) {
+      uint8_t* base = lds + slot * A_BYTES + 8 * wave * LBK;
+#pragma unroll
+      for (int r = 0; r < A_ROUNDS; ++r)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(a + k0 + a_voff[r]),
+            (__attribute__((address_space(3))) void*)(base + RPR * r * LBK), 16, 0, 0);
+    };
+    auto load_w = [&](int slot, int k0) {
+      uint8_t* base = lds + slot * W_BYTES + 8 * wave * LBK;
+#pragma unroll
+      for (int r = 0; r < W_ROUNDS; ++r)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(b + k0 + w_voff[r]),
+            (__attribute__((address_space(3))) void*)(base + RPR * r * LBK), 16, 0, 0);
+    };
+    // issue order A0 W0 A1 | W1 A2 | W2 A3 | ..: block g sits in slots 2g, 2g+1 (mod 5); behind
+    // barrier g the slots of block g-1 take W(g+1) and A(g+2); A(g+1) is the one half stage
+    // that is still in flight when barrier g is reached
+    load_a(0, 0);
+    load_w(1, 0);
+    if (ng > 1) load_a(2, LBK);
+    int sa = 0;   // slot of A(g)
+    for (int g = 0; g < ng; ++g) {
+      if (g + 1 < ng) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ROUNDS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int sw = sa + 1 >= 5 ? sa - 4 : sa + 1;
+      const int sw1 = sa + 3 >= 5 ? sa - 2 : sa + 3, sa2 = sa + 4 >= 5 ? sa - 1 : sa + 4;
+      const uint32_t wa0 = w_addr[0] - A_BYTES + sw * W_BYTES, wa1 = w_addr[1] - A_BYTES + sw * W_BYTES;
+      const uint32_t aa0 = a_addr[0] + sa * A_BYTES, aa1 = a_addr[1] + sa * A_BYTES;
+      i32x4 wl[NT], wh[NT], al[2], ah[2];
+      i32x8 wf[NT];
+      block_start<0>(wa0, wa1, aa0, aa1, wl, wh, al[0], ah[0]);
+      if (g + 1 < ng) load_w(sw1, (g + 1) * LBK);
+      if (g + 2 < ng) load_a(sa2, (g + 2) * LBK);
+      sa = sa + 2 >= 5 ? sa - 3 : sa + 2;
+      static_for<MT>([&](auto ic) {
+        constexpr int mt = decltype(ic)::value;
+        constexpr bool more = mt + 1 < MT;
+        if constexpr (more) lds_read_frag<0, mt + 1>(aa0, aa1, al[(mt + 1) & 1], ah[(mt + 1) & 1]);
+        constexpr int later = more ? 2 : 0;
+        if constexpr (mt == 0) {
+          if constexpr (WA < NT) lds_read_frag<0, WA>(wa0, wa1, wl[WA], wh[WA]);
+          wait_wa<later + 2 * w_younger<NT>(0)>(wl[0], wh[0], al[0], ah[0]);
+          const i32x8 af = cat8(al[0], ah[0]);
+          wf[0] = cat8(wl[0], wh[0]);
+          acc[0][0] = mm_mfma(wf[0], af, acc[0][0]);
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<NT - 1>([&](auto jc) {
+            constexpr int nt = decltype(jc)::value + 1;
+            if constexpr (nt + WA < NT) lds_read_frag<0, nt + WA>(wa0, wa1, wl[nt + WA], wh[nt + WA]);
+            wait_frag<(nt < WA ? later : 0) + 2 * w_younger<NT>(nt)>(wl[nt], wh[nt]);
+            wf[nt] = cat8(wl[nt], wh[nt]);
+            acc[nt][0] = mm_mfma(wf[nt], af, acc[nt][0]);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        } else {
+          wait_frag<later>(al[mt & 1], ah[mt & 1]);
+          const i32x8 af = cat8(al[mt & 1], ah[mt & 1]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = mm_mfma(wf[nt], af, acc[nt][mt]);
+        }
+      });
+    }
+  }
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (s < ng) group_load(s, s);
+    if (!R5 && s < ng) group_load(s, s);
   int cur = 0, nxt = NST - 1;   // buffer of group g / of group g + NST - 1
-  for (int g = 0; g < ng; ++g) {
+  for (int g = 0; !R5 && g < ng; ++g) {
     // own DMA of group g has landed (in the steady state everything but the NST-2 younger
     // groups; near the end fewer are in flight, so drain); then everybody's has, and
     // everybody is done reading the buffer that is restaged next
@@ -331,10 +413,12 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
         block_start<kb1 * STAGE>(wa0, wa1, aa0, aa1, wl[kb1 & 1], wh[kb1 & 1], al[s1 & 1], ah[s1 & 1]);
       else if constexpr (more)
         lds_read_frag<kb1 * STAGE, mt1>(aa0, aa1, al[s1 & 1], ah[s1 & 1]);
-      constexpr int later = next_block ? 2 + 2 * NT : (more ? 2 : 0);
+      constexpr int later = next_block ? 2 + 2 * WA : (more ? 2 : 0);
       if constexpr (mt == 0) {
-        // reads of this block in issue order: W0 A0 W1 .. W(NT-1), then `later` younger ones
-        wait_wa<later + 2 * (NT - 1)>(wl[kb & 1][0], wh[kb & 1][0], al[s & 1], ah[s & 1]);
+        // reads of this block in issue order: W0 A0 W1 .. W(WA-1), the `later` reads of the next
+        // step, then W(WA) .. W(NT-1), one in front of each MFMA
+        if constexpr (WA < NT) lds_read_frag<kb * STAGE, WA>(wa0, wa1, wl[kb & 1][WA], wh[kb & 1][WA]);
+        wait_wa<later + 2 * w_younger<NT>(0)>(wl[kb & 1][0], wh[kb & 1][0], al[s & 1], ah[s & 1]);
         const i32x8 af = cat8(al[s & 1], ah[s & 1]);
         wf[0] = cat8(wl[kb & 1][0], wh[kb & 1][0]);
         acc[0][mt] = mm_mfma(wf[0], af, acc[0][mt]);
@@ -343,7 +427,10 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
         __builtin_amdgcn_sched_barrier(0);
         static_for<NT - 1>([&](auto jc) {
           constexpr int nt = decltype(jc)::value + 1;
-          wait_frag<later + 2 * (NT - 1 - nt)>(wl[kb & 1][nt], wh[kb & 1][nt]);
+          if constexpr (nt + WA < NT)
+            lds_read_frag<kb * STAGE, nt + WA>(wa0, wa1, wl[kb & 1][nt + WA], wh[kb & 1][nt + WA]);
+          // W(nt) is older than the next step's reads only while it belongs to the up-front ones
+          wait_frag<(nt < WA ? later : 0) + 2 * w_younger<NT>(nt)>(wl[kb & 1][nt], wh[kb & 1][nt]);
           wf[nt] = cat8(wl[kb & 1][nt], wh[kb & 1][nt]);
           acc[nt][mt] = mm_mfma(wf[nt], af, acc[nt][mt]);
           __builtin_amdgcn_sched_barrier(0);
@@ -459,7 +546,7 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
     constexpr int SWZ = (CPR < 8 ? CPR : 8) - 1; // chunk ^= row & SWZ stays inside the row
     constexpr int RPI = 64 / CPR;                // rows per store instruction
     static_assert(BM % (RPI * NW) == 0, "");
-    static_assert(BM * ROWB <= NST * KB * STAGE, "");
+    static_assert(BM * ROWB <= LDS_TOTAL, "");
     __syncthreads();   // every wave is past its last fragment read
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -629,6 +716,8 @@ static int launch_glds_shape(int shape, const GldsArgs& g) {
     case 9: return launch_glds_t<out_t, 64, 32, 2, 2, 4, 1, true>(g);
     case 10: return launch_glds_t<out_t, 64, 32, 2, 2, 3, 4, true>(g);
     case 12: return launch_glds_t<out_t, 32, 128, 1, 4, 4, 1, true>(g);
+    case 14: return launch_glds_t<out_t, 256, 256, 2, 2, 2, 1, false>(g);   // 4 waves, 128 x 128 each
+    case 15: return launch_glds_t<out_t, 256, 256, 2, 4, 5, 1, false>(g);   // ring of five half stages
     default: return launch_glds_t<out_t, 32, 128, 1, 4, 3, 2, true>(g);   // 13
   }
 }
@@ -647,8 +736,8 @@ int launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
                            int out_dtype, bool vec, int splits, int ws_mode, hipStream_t st) {
   // shape = a GldsTile::id of the table in scaled_mm.hip.  Shapes that consume KB blocks per
   // barrier need K % (128 KB) == 0; otherwise the same tile with KB = 1.
-  static const int kb_of[14] = {1, 1, 1, 1, 2, 1, 2, 1, 4, 1, 4, 1, 1, 2};
-  if (shape < 2 || shape > 13 || shape == 11) shape = 3;
+  static const int kb_of[16] = {1, 1, 1, 1, 2, 1, 2, 1, 4, 1, 4, 1, 1, 2, 1, 1};
+  if (shape < 2 || shape > 15 || shape == 11) shape = 3;
   if (K % (LBK * kb_of[shape]) != 0) shape -= 1;
   const GldsArgs g{out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc, asn, bsn, vec, st,
                    splits, ws_mode};
