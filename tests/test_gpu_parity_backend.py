@@ -135,3 +135,140 @@ def test_profiling_run_and_unsupported():
         TritonAttentionImpl(8, 80, 0.1, 2, None, None, "auto")
     with pytest.raises(NotImplementedError, match="Encoder self-attention"):
         TritonAttentionImpl(8, 128, 0.1, 2, None, None, "auto", attn_type="encoder")
+
+
+# ---- V0 engine: ROCmFlashAttentionBackend / Impl (vllm/attention/backends/rocm_flash_attn.py) ----
+V0_SEQS = [(70, 70), (33, 200), (9, 9), (150, 1100), (2, 2), (17, 80), (5, 600),        # prefills first
+           (1, 500), (1, 64), (1, 1), (1, 129), (1, 31), (1, 1000), (1, 333), (1, 65), (1, 256)]
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("heads", [(8, 2), (32, 8)])
+@pytest.mark.parametrize("mode", ["plain", "alibi", "fp8_out"])
+def test_rocm_flash_attention_impl_forward(oracle, fp8, heads, mode):
+    """ROCmFlashAttentionImpl.forward on |prefill chunks|decode tokens|: cache write (x layout)
+    bit-exact with the oracle's reshape_and_cache, prefill rows against the oracle's
+    context_attention_fwd, decode rows against its attention over the written cache."""
+    from vllm_amd.attention.backends.rocm_flash_attn import (ROCmFlashAttentionBackend,
+                                                             ROCmFlashAttentionImpl,
+                                                             ROCmFlashAttentionMetadata)
+    assert ROCmFlashAttentionBackend.get_name() == "ROCM_FLASH"
+    assert ROCmFlashAttentionBackend.get_impl_cls() is ROCmFlashAttentionImpl
+    H, KVH, D, BS, dtype = heads[0], heads[1], 128, 16, torch.bfloat16
+    c = make_unified_case(V0_SEQS, H, KVH, D, BS, dtype, fp8=fp8, seed=3 * H + fp8, kv_scale=0.5)
+    T = c["q"].shape[0]
+    npf = sum(1 for ql, _ in V0_SEQS if ql > 1)
+    npf_tok = sum(ql for ql, _ in V0_SEQS if ql > 1)
+    g = torch.Generator().manual_seed(11)
+    key = torch.randn((T, KVH, D), generator=g).to(dtype)
+    value = torch.randn((T, KVH, D), generator=g).to(dtype)
+    slots = []
+    for b, (ql, kl) in enumerate(V0_SEQS):
+        for pos in range(kl - ql, kl):
+            slots.append(int(c["block_table"][b, pos // BS]) * BS + pos % BS)
+    slots = torch.tensor(slots, dtype=torch.int64)
+    kvd = "fp8" if fp8 else "auto"
+    sc = float(c["scale"]) if fp8 else 1.0
+    slopes = [2.0 ** -(0.25 * i + 1) for i in range(H)] if mode == "alibi" else None
+    slopes_t = None if slopes is None else torch.tensor(slopes)
+
+    kc_o, vc_o = c["k"].clone(), c["v"].clone()
+    oracle.reshape_and_cache_flash(key, value, kc_o, vc_o, slots, kvd, sc, sc)
+    ref = torch.zeros((T, H, D), dtype=dtype)
+    kd = c["scale"] if fp8 else None
+    oracle.unified_attention(c["q"], kc_o, vc_o, ref, c["cu_seqlens_q"], c["max_seqlen_q"], c["seqused_k"],
+                             c["max_seqlen_k"], D ** -0.5, True, (-1, -1), c["block_table"], 0.0, None, kd, kd,
+                             slopes_t, None)
+    kx_o, vx_o = _to_x_layout(kc_o, vc_o)
+    ref_pf = torch.zeros_like(ref)
+    oracle.context_attention_fwd(c["q"], key, value, ref_pf, kvd, kx_o, vx_o, c["block_table"],
+                                 c["cu_seqlens_q"], c["seqused_k"], c["max_seqlen_k"], c["max_seqlen_q"],
+                                 sc, sc, slopes_t, None, D ** -0.5)
+    ref[:npf_tok] = ref_pf[:npf_tok]
+
+    dev = torch.device("cuda", 0)
+    shape = ROCmFlashAttentionBackend.get_kv_cache_shape(c["k"].shape[0], BS, KVH, D)
+    kx, vx = _to_x_layout(c["k"], c["v"])
+    kv_cache = torch.stack([kx.reshape(kx.shape[0], -1), vx.reshape(vx.shape[0], -1)]).to(dev)
+    assert tuple(kv_cache.shape) == shape
+    layer = types.SimpleNamespace(_k_scale=torch.tensor(sc, device=dev), _v_scale=torch.tensor(sc, device=dev))
+    kvl = c["seqused_k"]
+    md = ROCmFlashAttentionMetadata(
+        seq_lens_tensor=kvl.to(dev), max_decode_seq_len=int(kvl[npf:].max()),
+        block_tables=c["block_table"].to(dev), num_prefills=npf, num_prefill_tokens=npf_tok,
+        num_decode_tokens=T - npf_tok, slot_mapping=slots.to(dev), seq_lens=kvl.tolist(),
+        max_prefill_seq_len=int(kvl[:npf].max()), max_query_len=c["max_seqlen_q"],
+        query_start_loc=c["cu_seqlens_q"].to(dev),
+        seq_start_loc=torch.cat([torch.zeros(1, dtype=torch.int32), kvl.cumsum(0).to(torch.int32)]).to(dev),
+        context_lens_tensor=(kvl - torch.tensor([q for q, _ in V0_SEQS], dtype=torch.int32)).to(dev))
+    assert md.decode_metadata.block_tables.shape[0] == len(V0_SEQS) - npf
+    assert md.prefill_metadata.query_start_loc.shape[0] == npf + 1
+    impl = ROCmFlashAttentionImpl(H, D, D ** -0.5, KVH, slopes, None, kvd)
+    out_scale = torch.tensor([0.05], device=dev) if mode == "fp8_out" else None
+    output = torch.zeros((T, H * D), dtype=torch.float8_e4m3fn if out_scale is not None else dtype, device=dev)
+    ret = impl.forward(layer, c["q"].reshape(T, H * D).to(dev), key.reshape(T, KVH * D).to(dev),
+                       value.reshape(T, KVH * D).to(dev), kv_cache, md, output=output, output_scale=out_scale)
+    torch.cuda.synchronize()
+    assert ret.shape == (T, H * D) and ret.data_ptr() == output.data_ptr()
+    bits = lambda t: t.contiguous().view(torch.int16 if t.element_size() == 2 else torch.uint8)
+    assert torch.equal(bits(kv_cache[0].cpu().view(kx_o.shape)), bits(kx_o))
+    assert torch.equal(bits(kv_cache[1].cpu().view(vx_o.shape)), bits(vx_o))
+    got = output.cpu().float().view(T, H, D)
+    if out_scale is None:
+        torch.testing.assert_close(got, ref.float(), atol=1.5e-2, rtol=1e-2)
+    else:
+        # fp8 output = quantise(attention / scale): compare dequantised, one e4m3 step of slack
+        torch.testing.assert_close(got * 0.05, ref.float(), atol=1.5e-2 + 0.05 * 0.07, rtol=7e-2)
+
+
+@pytest.mark.parametrize("window", [None, 48])
+def test_rocm_flash_attention_prompt_run_without_block_tables(oracle, window):
+    """Prompt run before any block table exists (rocm_flash_attn.py:779-860; the profiling run
+    has no kv cache at all): q and k are the prompts themselves."""
+    from vllm_amd.attention.backends.rocm_flash_attn import ROCmFlashAttentionImpl, ROCmFlashAttentionMetadata
+    H, KVH, D, dtype = 8, 2, 128, torch.float16
+    lens = [37, 128, 5, 300]
+    T = sum(lens)
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn((T, H, D), generator=g).to(dtype)
+    k = torch.randn((T, KVH, D), generator=g).to(dtype)
+    v = torch.randn((T, KVH, D), generator=g).to(dtype)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    # expected: fp32 causal (+ local) attention per prompt
+    ref = torch.zeros((T, H, D))
+    for b, n in enumerate(lens):
+        lo = int(cu[b])
+        qq = q[lo:lo + n].float().transpose(0, 1)
+        kk = k[lo:lo + n].float().repeat_interleave(H // KVH, 1).transpose(0, 1)
+        vv = v[lo:lo + n].float().repeat_interleave(H // KVH, 1).transpose(0, 1)
+        s = qq @ kk.transpose(1, 2) * D ** -0.5
+        i, j = torch.arange(n)[:, None], torch.arange(n)[None, :]
+        mask = j > i
+        if window is not None:
+            mask |= j <= i - window
+        s.masked_fill_(mask, float("-inf"))
+        ref[lo:lo + n] = (torch.softmax(s, -1) @ vv).transpose(0, 1)
+    dev = torch.device("cuda", 0)
+    md = ROCmFlashAttentionMetadata(
+        seq_lens_tensor=torch.tensor(lens, dtype=torch.int32, device=dev), max_decode_seq_len=0,
+        block_tables=torch.empty((len(lens), 0), dtype=torch.int32, device=dev), num_prefills=len(lens),
+        num_prefill_tokens=T, num_decode_tokens=0, slot_mapping=torch.zeros(T, dtype=torch.int64, device=dev),
+        seq_lens=lens, max_prefill_seq_len=max(lens), max_query_len=max(lens), query_start_loc=cu.to(dev),
+        seq_start_loc=cu.to(dev), context_lens_tensor=torch.zeros(len(lens), dtype=torch.int32, device=dev))
+    layer = types.SimpleNamespace(_k_scale=torch.tensor(1.0, device=dev), _v_scale=torch.tensor(1.0, device=dev))
+    impl = ROCmFlashAttentionImpl(H, D, D ** -0.5, KVH, None, window, "auto")
+    output = torch.zeros((T, H * D), dtype=dtype, device=dev)
+    impl.forward(layer, q.view(T, -1).to(dev), k.view(T, -1).to(dev), v.view(T, -1).to(dev),
+                 torch.empty(0, device=dev), md, output=output)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(output.cpu().float().view(T, H, D), ref, atol=2e-3, rtol=2e-3)
+
+
+def test_rocm_flash_attention_impl_rejects():
+    from vllm_amd.attention.backends.rocm_flash_attn import ROCmFlashAttentionImpl
+    with pytest.raises(ValueError, match="Head size 100 is not supported by PagedAttention"):
+        ROCmFlashAttentionImpl(8, 100, 0.1, 2, None, None, "auto")
+    with pytest.raises(NotImplementedError, match="KV sharing is not supported"):
+        ROCmFlashAttentionImpl(8, 128, 0.1, 2, None, None, "auto", kv_sharing_target_layer_name="x")
+    with pytest.raises(NotImplementedError, match="decoder self-attention only"):
+        ROCmFlashAttentionImpl(8, 128, 0.1, 2, None, None, "auto", attn_type="encoder")
