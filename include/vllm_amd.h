@@ -105,6 +105,24 @@ int vllm_amd_paged_attention_rocm(
     int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
     void* stream);
 
+/* The decode side of chunked_prefill_paged_decode when a sliding window is set: the
+ * reference's Triton kernel_paged_attention_2d (vllm/attention/ops/chunked_prefill_paged_decode.py
+ * :27-212, launched at :340-381; its custom op has no window, platforms/rocm.py:139-140).
+ * Arguments of vllm_amd_paged_attention_rocm plus sliding_window (<= 0: none): the token at
+ * position seq_len - 1 attends to the keys [seq_len - sliding_window, seq_len) (:167-171).
+ * Sequences whose query length is not 1 are skipped when query_start_loc is given (:71-78);
+ * fp8_out_scale as :201-203.  Scratch as the rocm op (partition 256). */
+int vllm_amd_paged_attention_2d(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int* block_tables, const int* seq_lens, const int* query_start_loc,
+    int max_num_blocks_per_seq, int block_size, int max_seq_len,
+    int max_num_partitions, const float* alibi_slopes, int dtype, int kv_dtype,
+    const float* k_scale, const float* v_scale, const float* fp8_out_scale,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int sliding_window, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* KV-cache writes                                                            */
 /* ------------------------------------------------------------------------- */

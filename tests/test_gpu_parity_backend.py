@@ -31,8 +31,8 @@ def _to_x_layout(kc_f, vc_f):
 @pytest.mark.parametrize("heads", [(8, 2), (32, 8)])
 @pytest.mark.parametrize("mode", ["plain", "alibi", "window", "softcap"])
 def test_triton_attention_impl_forward(oracle, monkeypatch, path, fp8, heads, mode):
-    if path == "prefill_decode" and mode in ("window", "softcap"):
-        pytest.skip("the prefill + paged-decode path has no decode-side window / soft cap")
+    if path == "prefill_decode" and mode == "softcap":
+        pytest.skip("the prefill + paged-decode path has no soft cap (nor has the reference's)")
     from vllm_amd.v1.attention.backends import (TritonAttentionBackend, TritonAttentionImpl,
                                                 TritonAttentionMetadataBuilder)
     monkeypatch.setenv("VLLM_V1_USE_PREFILL_DECODE_ATTENTION", "1" if path == "prefill_decode" else "0")
@@ -62,7 +62,11 @@ def test_triton_attention_impl_forward(oracle, monkeypatch, path, fp8, heads, mo
     kc_o, vc_o = c["k"].clone(), c["v"].clone()
     oracle.reshape_and_cache_flash(key[:T], value[:T], kc_o, vc_o, slots[:T], kvd, sc, sc)
     ref = torch.zeros((T, H, D), dtype=dtype)
-    ws = (window - 1, 0) if window is not None else (-1, -1)
+    # the reference hands `self.sliding_window[0]` = window - 1 to chunked_prefill_paged_decode
+    # (triton_attn.py:349), whose kernels keep the keys with q_pos - k_pos < that value: one key
+    # fewer than unified_attention's window_size = (window - 1, 0).  Mirrored as is.
+    weff = None if window is None else (window - 1 if path == "prefill_decode" else window)
+    ws = (weff - 1, 0) if window is not None else (-1, -1)
     kd = c["scale"] if fp8 else None
     oracle.unified_attention(c["q"], kc_o, vc_o, ref, c["cu_seqlens_q"], c["max_seqlen_q"],
                              c["seqused_k"], c["max_seqlen_k"], D ** -0.5, True, ws, c["block_table"],
@@ -76,7 +80,7 @@ def test_triton_attention_impl_forward(oracle, monkeypatch, path, fp8, heads, mo
         ref_pf = torch.zeros_like(ref)
         oracle.context_attention_fwd(c["q"], key[:T], value[:T], ref_pf, kvd, kx_o, vx_o, c["block_table"],
                                      c["cu_seqlens_q"], c["seqused_k"], c["max_seqlen_k"], c["max_seqlen_q"],
-                                     sc, sc, None if slopes is None else torch.tensor(slopes), None,
+                                     sc, sc, None if slopes is None else torch.tensor(slopes), weff,
                                      D ** -0.5)
         for b, (ql, _) in enumerate(SEQS):
             if ql > 1:
@@ -272,3 +276,44 @@ def test_rocm_flash_attention_impl_rejects():
         ROCmFlashAttentionImpl(8, 128, 0.1, 2, None, None, "auto", kv_sharing_target_layer_name="x")
     with pytest.raises(NotImplementedError, match="decoder self-attention only"):
         ROCmFlashAttentionImpl(8, 128, 0.1, 2, None, None, "auto", attn_type="encoder")
+
+
+# ---- decode side of chunked_prefill_paged_decode with a sliding window ----------------------
+@pytest.mark.parametrize("window", [1, 40, 256, 700, 5000])
+@pytest.mark.parametrize("shape", [(32, 8, 128, 16, True), (8, 2, 128, 16, False), (4, 4, 64, 32, True),
+                                   (8, 8, 256, 16, False), (16, 1, 96, 16, False)])
+@pytest.mark.parametrize("mode", ["plain", "alibi", "fp8_out"])
+def test_paged_decode_sliding_window(oracle, window, shape, mode):
+    """vllm_amd_paged_attention_2d (kernel_paged_attention_2d, chunked_prefill_paged_decode.py:27-212):
+    decode tokens see the last `window` keys only; windows inside one partition, across partitions,
+    longer than the sequence; MFMA path (head <= 128) and generic path (head 256); the mixed batch's
+    prefill chunks are skipped through query_start_loc."""
+    from vllm_amd.attention.ops.chunked_prefill_paged_decode import chunked_prefill_paged_decode
+    H, KVH, D, BS, fp8 = shape
+    dtype = torch.bfloat16
+    seqs = [(1, 1), (1, 39), (1, 40), (1, 41), (1, 255), (1, 256), (1, 257), (1, 700), (1, 1300), (1, 2049),
+            (1, 3000), (1, 513)]
+    c = make_unified_case(seqs, H, KVH, D, BS, dtype, fp8=fp8, seed=window + H, kv_scale=0.5)
+    T = len(seqs)
+    slopes = torch.tensor([2.0 ** -(0.25 * i + 1) for i in range(H)]) if mode == "alibi" else None
+    kd = c["scale"] if fp8 else None
+    ref = torch.zeros((T, H, D), dtype=dtype)
+    oracle.unified_attention(c["q"], c["k"], c["v"], ref, c["cu_seqlens_q"], 1, c["seqused_k"],
+                             c["max_seqlen_k"], D ** -0.5, True, (window - 1, 0), c["block_table"], 0.0,
+                             None, kd, kd, slopes, None)
+    dev = torch.device("cuda", 0)
+    kx, vx = _to_x_layout(c["k"], c["v"])
+    out_scale = torch.tensor([0.04], device=dev) if mode == "fp8_out" else None
+    out = torch.zeros((T, H, D), dtype=torch.float8_e4m3fn if out_scale is not None else dtype, device=dev)
+    sc = torch.tensor(float(c["scale"]) if fp8 else 1.0, device=dev)
+    key = torch.zeros((T, KVH, D), dtype=dtype, device=dev)   # shapes only: max_query_len == 1
+    chunked_prefill_paged_decode(c["q"].to(dev), key, key, out, "fp8" if fp8 else "auto", kx.to(dev), vx.to(dev),
+                                 c["block_table"].to(dev), c["cu_seqlens_q"].to(dev), c["seqused_k"].to(dev),
+                                 c["max_seqlen_k"], 1, sc, sc, None if slopes is None else slopes.to(dev),
+                                 window, D ** -0.5, out_scale)
+    torch.cuda.synchronize()
+    got = out.cpu().float()
+    if out_scale is None:
+        torch.testing.assert_close(got, ref.float(), atol=1.5e-2, rtol=1e-2)
+    else:
+        torch.testing.assert_close(got * 0.04, ref.float(), atol=1.5e-2 + 0.04 * 0.07, rtol=7e-2)

@@ -29,6 +29,9 @@ SIGNATURES = {
     "vllm_amd_paged_attention_rocm": [
         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _i, _i,
         _vp, _i, _i, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
+    "vllm_amd_paged_attention_2d": [
+        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _i, _i,
+        _vp, _i, _i, _vp, _vp, _vp, _i64, _i64, _i64, _i, _vp],
     "vllm_amd_reshape_and_cache": [
         _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i, _i, _vp, _vp, _vp],
     "vllm_amd_reshape_and_cache_flash": [

@@ -29,6 +29,7 @@ struct PagedAttnParams {
   int64_t q_stride, kv_block_stride, kv_head_stride;
   int tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step;
   bool rocm_semantics;  // reduce order / out indexing of csrc/rocm/attention.cu
+  int window = 0;       // sliding window of the decode token, 0 = none (vllm_amd_paged_attention_2d)
   hipStream_t stream;
 };
 

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kGenThreads) void pa_generic_kernel(
     int64_t kv_head_stride, const float* __restrict__ k_scale_p,
     const float* __restrict__ v_scale_p, int head_size, int block_size, int partition_size,
     int tp_rank, int bs_local_blocks, int bs_vert_stride, int bs_block_size,
-    int bs_head_sliding_step) {
+    int bs_head_sliding_step, int window) {
   constexpr int X = CacheTraits<cache_t>::X;
   constexpr bool FP8 = sizeof(cache_t) == 1;
   const int head = blockIdx.x, seq = blockIdx.y, part = blockIdx.z;
@@ -101,8 +101,12 @@ __global__ __launch_bounds__(kGenThreads) void pa_generic_kernel(
 
   const int num_seq_blocks = (seq_len + block_size - 1) / block_size;
   const int nbpp = partitioned ? partition_size / block_size : num_seq_blocks;
-  const int start_block = partitioned ? part * nbpp : 0;
-  const int end_block = min(start_block + nbpp, num_seq_blocks);
+  // sliding window: tokens in front of first_tok are masked; partitions entirely in front of it
+  // write nothing (the reduce kernel starts at the window's first partition)
+  const int first_tok = window > 0 ? max(0, seq_len - window) : 0;
+  if (partitioned && min((part + 1) * partition_size, seq_len) <= first_tok) return;
+  const int end_block = min((partitioned ? part * nbpp : 0) + nbpp, num_seq_blocks);
+  const int start_block = max(partitioned ? part * nbpp : 0, first_tok / block_size);
   const int nblocks = end_block - start_block;
   const int start_tok = start_block * block_size;
   const int end_tok = min(start_tok + nblocks * block_size, seq_len);
@@ -167,6 +171,7 @@ __global__ __launch_bounds__(kGenThreads) void pa_generic_kernel(
       lg = acc * qk_scale;
       if (slope != 0.f) lg += slope * (float)(tok - seq_len + 1);
       if (tok >= seq_len) lg = 0.f;          // masked tail, :296-298
+      else if (tok < first_tok) lg = -FLT_MAX;
       else qk_max = fmaxf(qk_max, lg);
     }
     logits[i] = lg;
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(128) void pa_reduce_kernel(
     const float* __restrict__ max_logits, const scalar_t* __restrict__ tmp_out,
     const int* __restrict__ seq_lens, const int* __restrict__ query_start_loc,
     const float* __restrict__ fp8_out_scale, int head_size, int partition_size,
-    int max_num_partitions, int slot_stride) {
+    int max_num_partitions, int slot_stride, int window) {
   const int head = blockIdx.x, seq = blockIdx.y, num_heads = gridDim.x;
   const int tid = threadIdx.x;
   int64_t orow = seq;
@@ -259,8 +264,10 @@ __global__ __launch_bounds__(128) void pa_reduce_kernel(
   }
   const int seq_len = seq_lens[seq];
   // partition_size = tokens per USED scratch slot; used slots are slot_stride apart
-  const int np = (seq_len + partition_size - 1) / partition_size;
-  const int64_t sidx = ((int64_t)seq * num_heads + head) * max_num_partitions;
+  // sliding window: the used slots in front of the window's first one were never written
+  const int j0 = window > 0 ? max(0, seq_len - window) / partition_size : 0;
+  const int np = (seq_len + partition_size - 1) / partition_size - j0;
+  const int64_t sidx = ((int64_t)seq * num_heads + head) * max_num_partitions + (int64_t)j0 * slot_stride;
   const scalar_t* tp = tmp_out + sidx * head_size;
   scalar_t* out = (scalar_t*)out_ + (orow * num_heads + head) * head_size;
   uint8_t* out8 = (uint8_t*)out_ + (orow * num_heads + head) * head_size;
@@ -325,12 +332,12 @@ static int launch_reduce(const PagedAttnParams& p) {
     hipLaunchKernelGGL((pa_reduce_kernel<scalar_t, true>), grid, dim3(128), smem, p.stream, p.out,
                        p.exp_sums, p.max_logits, (const scalar_t*)p.tmp_out, p.seq_lens,
                        p.query_start_loc, p.fp8_out_scale, p.head_size, p.partition_size * p.sp_parts,
-                       p.max_num_partitions, p.sp_parts);
+                       p.max_num_partitions, p.sp_parts, p.window);
   else
     hipLaunchKernelGGL((pa_reduce_kernel<scalar_t, false>), grid, dim3(128), smem, p.stream, p.out,
                        p.exp_sums, p.max_logits, (const scalar_t*)p.tmp_out, p.seq_lens,
                        p.query_start_loc, p.fp8_out_scale, p.head_size, p.partition_size * p.sp_parts,
-                       p.max_num_partitions, p.sp_parts);
+                       p.max_num_partitions, p.sp_parts, p.window);
   VA_LAUNCH_CHECK("paged_attention reduce launch");
   return VLLM_AMD_OK;
 }
@@ -370,7 +377,7 @@ static int launch_generic(const PagedAttnParams& p) {
                        p.seq_lens, p.query_start_loc, p.max_num_blocks_per_seq, p.alibi_slopes,   \
                        p.q_stride, p.kv_block_stride, p.kv_head_stride, p.k_scale, p.v_scale,     \
                        p.head_size, p.block_size, p.partition_size, p.tp_rank, p.bs_local_blocks, \
-                       p.bs_vert_stride, p.bs_block_size, p.bs_head_sliding_step);                \
+                       p.bs_vert_stride, p.bs_block_size, p.bs_head_sliding_step, p.window);      \
   } while (0)
   if (p.bs_vert_stride > 1) GEN(true); else GEN(false);
 #undef GEN
@@ -515,6 +522,40 @@ extern "C" int vllm_amd_paged_attention_rocm(
              "paged_attention: max_num_partitions %d too small for max_context_len %d",
              max_num_partitions, max_context_len);
   return run(p, "paged_attention");
+}
+
+// The decode side of chunked_prefill_paged_decode with a sliding window
+// (vllm/attention/ops/chunked_prefill_paged_decode.py:27-212 `kernel_paged_attention_2d`, launch
+// :340-381): the arguments of vllm_amd_paged_attention_rocm plus `sliding_window` (<= 0: none).
+// A decode token at position seq_len - 1 sees the keys [seq_len - sliding_window, seq_len).
+extern "C" int vllm_amd_paged_attention_2d(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+    const void* key_cache, const void* value_cache, int num_seqs, int num_heads, int head_size,
+    int num_kv_heads, float scale, const int* block_tables, const int* seq_lens,
+    const int* query_start_loc, int max_num_blocks_per_seq, int block_size, int max_seq_len,
+    int max_num_partitions, const float* alibi_slopes, int dtype, int kv_dtype,
+    const float* k_scale, const float* v_scale, const float* fp8_out_scale, int64_t q_stride,
+    int64_t kv_block_stride, int64_t kv_head_stride, int sliding_window, void* stream) {
+  PagedAttnParams p = {};
+  p.out = out; p.exp_sums = exp_sums; p.max_logits = max_logits; p.tmp_out = tmp_out;
+  p.query = query; p.key_cache = key_cache; p.value_cache = value_cache;
+  p.num_seqs = num_seqs; p.num_heads = num_heads; p.head_size = head_size;
+  p.num_kv_heads = num_kv_heads; p.scale = scale; p.block_tables = block_tables;
+  p.seq_lens = seq_lens; p.query_start_loc = query_start_loc;
+  p.max_num_blocks_per_seq = max_num_blocks_per_seq; p.block_size = block_size;
+  p.max_seq_len = max_seq_len; p.partition_size = 256;
+  p.max_num_partitions = max_num_partitions; p.alibi_slopes = alibi_slopes; p.dtype = dtype;
+  p.kv_dtype = kv_dtype; p.k_scale = k_scale; p.v_scale = v_scale;
+  p.fp8_out_scale = fp8_out_scale; p.q_stride = q_stride; p.kv_block_stride = kv_block_stride;
+  p.kv_head_stride = kv_head_stride; p.bs_block_size = 64; p.rocm_semantics = true;
+  p.window = sliding_window > 0 ? sliding_window : 0;
+  p.stream = (hipStream_t)stream;
+  VA_REQUIRE(dtype == VLLM_AMD_F16 || dtype == VLLM_AMD_BF16, VLLM_AMD_EUNSUPPORTED,
+             "Unsupported data type: %d", dtype);
+  VA_REQUIRE((int64_t)max_num_partitions * 256 >= max_seq_len, VLLM_AMD_EINVAL,
+             "paged_attention_2d: max_num_partitions %d too small for max_seq_len %d",
+             max_num_partitions, max_seq_len);
+  return run(p, "paged_attention_2d");
 }
 
 // Tuning knobs for A/B measurements in one process (not part of the reference surface).

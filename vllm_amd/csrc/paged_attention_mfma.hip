@@ -74,6 +74,7 @@ struct PaK {
   int partition_size, max_parts, gqa_chunks, slot_stride, dr_arg;
   // balanced launches (BAL): partial slots, ticket counters, batch size
   float* bal_ws; unsigned* bal_ctr; int num_seqs;
+  int window;   // sliding window of the decode token (0 = none): keys [seq_len - window, seq_len)
 };
 
 // What a workgroup does with one piece of one sequence: tokens [start_tok, end_tok) of `seq`.
@@ -83,6 +84,7 @@ struct PaK {
 //           ticket; the workgroup that draws the sequence's last ticket merges all its pieces -> out
 struct PaPiece {
   int seq; int64_t qrow; int start_tok, end_tok, seq_len; int mode; int part;
+  int first_tok = 0;   // tokens in front of it are masked (sliding window; start_tok is its step, rounded down)
   float* slot; const float* slots; unsigned* ticket; int jf, jl, pre, n_tot, gk;
 };
 
@@ -240,6 +242,9 @@ __device__ __forceinline__ void pa_piece(const PaK<scalar_t>& A, char* lds, cons
   auto do_step = [&](KRegs& kreg, VRegs& vreg, int step, int pf, auto more_c) {
     constexpr bool more = decltype(more_c)::value;   // this step is followed by step pf of the wave
     const int tok0 = start_tok + step * STEP_TOK;
+    // visible tokens: first_tok <= tok < end_tok, as ONE unsigned compare of (tok - first_tok)
+    const int tokr0 = tok0 - P.first_tok;
+    const unsigned span = (unsigned)(end_tok - P.first_tok);
 #ifdef VA_PROBES
     if constexpr ((VARIANT & 4) != 0) {   // ablation: the loads and their issue points only
       uint4 x = make_uint4(0, 0, 0, 0);
@@ -287,7 +292,7 @@ __device__ __forceinline__ void pa_piece(const PaK<scalar_t>& A, char* lds, cons
       for (int r = 0; r < 4; ++r) {
         const int tok = tok0 + 16 * t + 4 * g4 + r;
         float v = s[t][r] * sc2 + slope2 * (float)(tok - seq_len + 1);
-        v = tok < end_tok ? v : -FLT_MAX;
+        v = (unsigned)(tokr0 + 16 * t + 4 * g4 + r) < span ? v : -FLT_MAX;
         s[t][r] = v;
         mx = fmaxf(mx, v);
       }
@@ -304,9 +309,8 @@ __device__ __forceinline__ void pa_piece(const PaK<scalar_t>& A, char* lds, cons
       float p[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int tok = tok0 + 16 * t + 4 * g4 + r;
         float e = fast_exp2(s[t][r] - m_new);
-        e = tok < end_tok ? e : 0.f;
+        e = (unsigned)(tokr0 + 16 * t + 4 * g4 + r) < span ? e : 0.f;
         p[r] = e;
         psum += e;
       }
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
     int64_t kv_head_bytes, const float* __restrict__ k_scale_p,
     const float* __restrict__ v_scale_p, int partition_size, int max_parts, int gqa_chunks,
     int slot_stride_arg, int dr_arg, float* __restrict__ bal_ws, unsigned* __restrict__ bal_ctr,
-    int num_seqs) {
+    int num_seqs, int window) {
   VA_STAMP_DECL;
   VA_STAMP(0);
   // (the pointers stay __restrict__ kernel parameters: as members of a by-value struct they lose
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
   const PaK<scalar_t> A{out, exp_sums, max_logits, q, k_cache, v_cache, num_heads, num_kv_heads, scale,
                         block_tables, seq_lens, query_start_loc, max_num_blocks_per_seq, alibi_slopes,
                         q_stride, kv_block_bytes, kv_head_bytes, k_scale_p, v_scale_p, partition_size,
-                        max_parts, gqa_chunks, slot_stride_arg, dr_arg, bal_ws, bal_ctr, num_seqs};
+                        max_parts, gqa_chunks, slot_stride_arg, dr_arg, bal_ws, bal_ctr, num_seqs, window};
   constexpr int STEP_TOK = (FP8 ? 4 : 2) * 16;
   constexpr int P_BYTES = 16 * kPRowBytes;
   constexpr int MERGE_BYTES = NW * HEAD_SIZE * 16 * 4 + NW * 16 * 8;
@@ -576,6 +580,13 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
     P.start_tok = partitioned ? part * A.partition_size : 0;
     if (partitioned && P.start_tok >= P.seq_len) return;
     P.end_tok = partitioned ? min(P.start_tok + A.partition_size, P.seq_len) : P.seq_len;
+    if (A.window > 0) {
+      // sliding window: pieces in front of it write nothing (the reduce kernel starts at the
+      // window's first partition), the piece it starts in begins at the window's step
+      P.first_tok = max(0, P.seq_len - A.window);
+      if (partitioned && P.end_tok <= P.first_tok) return;
+      P.start_tok = max(P.start_tok, P.first_tok / STEP_TOK * STEP_TOK);
+    }
     P.mode = partitioned ? 1 : 0;
     P.part = part;
     PaK<scalar_t> B = A;
@@ -703,7 +714,7 @@ void set_pa_group(int v) { g_pa_group = v; }
       (A).num_kv_heads, (A).scale, (A).block_tables, (A).seq_lens, (A).query_start_loc,            \
       (A).max_num_blocks_per_seq, (A).alibi_slopes, (A).q_stride, (A).kv_block_bytes,              \
       (A).kv_head_bytes, (A).k_scale_p, (A).v_scale_p, (A).partition_size, (A).max_parts,          \
-      (A).gqa_chunks, (A).slot_stride, (A).dr_arg, (A).bal_ws, (A).bal_ctr, (A).num_seqs
+      (A).gqa_chunks, (A).slot_stride, (A).dr_arg, (A).bal_ws, (A).bal_ctr, (A).num_seqs, (A).window
 
 static int g_pa_balance = 0;   // tuning "pa_balance": 1 = balanced v1 launches whenever possible, else never
 void set_pa_balance(int v) { g_pa_balance = v; }
@@ -732,7 +743,7 @@ static int launch_mfma_v(const PagedAttnParams& p) {
   A.kv_head_bytes = p.kv_head_stride * es; A.k_scale_p = p.k_scale; A.v_scale_p = p.v_scale;
   A.partition_size = p.partition_size * sp; A.max_parts = p.max_num_partitions;
   A.gqa_chunks = chunks; A.slot_stride = group ? -sp : sp; A.dr_arg = p.head_size;
-  A.bal_ws = nullptr; A.bal_ctr = nullptr; A.num_seqs = p.num_seqs;
+  A.bal_ws = nullptr; A.bal_ctr = nullptr; A.num_seqs = p.num_seqs; A.window = p.window;
 
   // Balanced v1 launch (opt-in, "pa_balance" = 1): paged_attention_v1 has no scratch arguments,
   // so with one workgroup per (sequence, kv head) a skewed batch waits for its longest sequence.
@@ -743,7 +754,7 @@ static int launch_mfma_v(const PagedAttnParams& p) {
   // 5-7 us at the end of the launch, so it pays on skewed batches (one long sequence among many
   // short ones) and loses 2-7 us on uniform and mildly ragged ones -- the host cannot tell the
   // two apart (seq_lens live on the device), hence not the default.
-  if (!part && !p.query_start_loc && g_pa_balance == 1) {
+  if (!part && !p.query_start_loc && p.window == 0 && g_pa_balance == 1) {
     const int groups = p.num_kv_heads * chunks;
     const int64_t steps_ub = (int64_t)p.num_seqs * ceil_div(p.max_seq_len > 0 ? p.max_seq_len : 1, FP8 ? 64 : 32);
     int gk = 512 / groups;
