@@ -190,7 +190,7 @@ def test_validation_errors_of_the_neighbour_ops():
             0.1, window, softcap, 64, 4096, None, None, None, nseg, dtype, kv, None)
     assert ua(seqs=0) == 0
     assert "segment buffers" in _err(ua(nseg=16))
-    assert "unsupported head size: 256" in _err(ua(head_size=256))
+    assert "unsupported head size: 264" in _err(ua(head_size=264))
     assert "unsupported head size: 40" in _err(ua(head_size=40, kv=_lib.KV_FP8_E4M3, qs=320))
     assert "unsupported block size: 48" in _err(ua(block_size=48))
     assert "float16 or bfloat16" in _err(ua(dtype=_lib.F32))

@@ -1,7 +1,7 @@
 """GPU parity: unified_attention (flash-layout cache, causal, window / softcap / ALiBi / fp8)
 vs the CPU oracle's restatement of the Triton kernel.  Shapes and tolerance follow the
 reference's tests/kernels/attention/test_triton_unified_attention.py:80-200 (atol 1.5e-2,
-rtol 1e-2 on N(0,1) data); head size 256 of that test is outside this kernel (<= 128)."""
+rtol 1e-2 on N(0,1) data), head sizes 128 (tile / decode kernels) and 256 (wide-head kernel)."""
 import pytest
 import torch
 
@@ -47,11 +47,25 @@ def run(orc, c, dtype, window=None, softcap=0.0, alibi=None, out_scale=None, fp8
 @pytest.mark.parametrize("sliding_window", [None, 256])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("soft_cap", [None, 10.0, 50.0])
-def test_unified_reference_grid(oracle, seq_lens, num_heads, block_size, sliding_window, dtype, soft_cap):
-    """The reference test's grid at head size 128."""
-    c = make_unified_case(seq_lens, num_heads[0], num_heads[1], 128, block_size, dtype,
+@pytest.mark.parametrize("head_size", [128, 256])
+def test_unified_reference_grid(oracle, seq_lens, num_heads, block_size, sliding_window, dtype, soft_cap, head_size):
+    """The reference test's grid (HEAD_SIZES = [128, 256])."""
+    c = make_unified_case(seq_lens, num_heads[0], num_heads[1], head_size, block_size, dtype,
                           seed=len(seq_lens) + num_heads[0] + block_size)
     run(oracle, c, dtype, window=sliding_window, softcap=soft_cap or 0.0)
+
+
+@pytest.mark.parametrize("D", [160, 192, 224, 256])
+@pytest.mark.parametrize("mode", ["plain", "fp8", "alibi", "fp8_out"])
+def test_unified_wide_heads(oracle, D, mode):
+    """Head sizes 160 .. 256 of TritonAttentionBackend.get_supported_head_sizes (triton_attn.py:147-148):
+    the wide-head kernel, mixed batch, fp8 cache / ALiBi / fp8 output."""
+    fp8 = mode in ("fp8", "fp8_out")
+    c = make_unified_case([(90, 400), (1, 700), (17, 17), (1, 1), (3, 260)], 8, 2, D, 16, torch.bfloat16,
+                          fp8=fp8, seed=D, kv_scale=0.5)
+    slopes = 2.0 ** -(torch.arange(8).float() * 0.5 + 1) if mode == "alibi" else None
+    run(oracle, c, torch.bfloat16, fp8=fp8, alibi=slopes, window=300 if mode == "alibi" else None,
+        out_scale=torch.tensor([0.03]) if mode == "fp8_out" else None)
 
 
 @pytest.mark.parametrize("seq_lens", [[(700, 700), (300, 1500), (64, 64), (1, 1)], [(257, 1000), (130, 131)]])
@@ -265,7 +279,7 @@ def test_unified_strided_cache(oracle):
 
 def test_unified_rejects_what_it_does_not_cover():
     from vllm_amd.attention.ops import unified_attention
-    c = make_unified_case([(4, 40)], 4, 4, 256, 16, torch.bfloat16)
+    c = make_unified_case([(4, 40)], 4, 4, 264, 16, torch.bfloat16)
     out = torch.zeros(c["q"].shape, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(RuntimeError, match="unsupported head size"):
         unified_attention(c["q"].cuda(), c["k"].cuda(), c["v"].cuda(), out, c["cu_seqlens_q"].cuda(),

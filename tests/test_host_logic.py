@@ -146,8 +146,9 @@ def test_v1_backend_host_logic():
     assert B.use_cascade_attention() is False
     assert B.get_kv_cache_stride_order() == (0, 1, 3, 2, 4)   # head-major memory by default
     assert torch.bfloat16 in B.get_supported_dtypes() and 128 in B.get_supported_head_sizes()
-    with pytest.raises(ValueError, match="Head size 256 is not supported by TritonAttention"):
-        B.validate_head_size(256)
+    assert B.get_supported_head_sizes() == [32, 64, 96, 128, 160, 192, 224, 256]   # triton_attn.py:147-148
+    with pytest.raises(ValueError, match="Head size 80 is not supported by TritonAttention"):
+        B.validate_head_size(80)
 
     common = types.SimpleNamespace(
         num_actual_tokens=7, max_query_len=5, query_start_loc=torch.tensor([0, 5, 6, 7], dtype=torch.int32),

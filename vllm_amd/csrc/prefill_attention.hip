@@ -938,6 +938,113 @@ extern "C" int vllm_amd_context_attention_fwd(
 
 // unified_attention (vllm/attention/ops/triton_unified_attention.py:588-700): q over the new
 // tokens of every sequence, all keys / values from the flash-layout cache, causal.
+
+// ---------------------------------------------------------------------------------------
+// unified_attention for head sizes the tile kernel does not take (136 .. 256; the reference lists
+// 160 / 192 / 224 / 256, triton_attn.py:147-148): a plain VALU kernel, one workgroup (256 threads)
+// per (query token, q head) -- chunks of 256 keys, one key per thread for the scores, one output
+// column per thread for P V, online softmax across chunks.  Same masks and bias as the tile
+// kernel (triton_unified_attention.py:219-238).  Functional coverage, not a tuned path.
+// ---------------------------------------------------------------------------------------
+template <typename T, bool FP8>
+__global__ __launch_bounds__(256) void unified_wide_kernel(PrefillParams p, int num_seqs, int head_size,
+                                                         int block_size) {
+  const int tok = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+  // sequence of this token (find_seq_idx, :33-48)
+  int lo = 0, hi = num_seqs;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (p.b_start_loc[mid] <= tok) lo = mid; else hi = mid - 1;
+  }
+  const int b = lo;
+  if (b >= num_seqs || tok >= p.b_start_loc[num_seqs]) return;
+  const int q_len = p.b_start_loc[b + 1] - p.b_start_loc[b];
+  const int kv_len = p.b_seq_len[b];
+  const int qpos = kv_len - q_len + (tok - p.b_start_loc[b]);
+  const int kvh = head / (p.num_heads / p.num_kv_heads);
+  constexpr int ES = FP8 ? 1 : 2;
+  const float kscale = FP8 ? *p.k_scale : 1.f, vscale = FP8 ? *p.v_scale : 1.f;
+  const float slope = p.alibi_slopes ? p.alibi_slopes[head] : 0.f;
+  const int window = p.sliding_window;
+  const int first = window > 0 ? max(0, qpos - window + 1) : 0;   // visible keys: [first, qpos]
+
+  __shared__ float q_s[256];
+  __shared__ float p_s[256];
+  __shared__ float red[8];
+  const T* qp = (const T*)p.q + (int64_t)tok * p.q_stride_t + (int64_t)head * p.q_stride_h;
+  if (tid < head_size) q_s[tid] = to_f32(qp[tid]);
+  __syncthreads();
+  auto block_max = [&](float v) {
+    v = wave_max(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return v;
+  };
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = v;
+    __syncthreads();
+    v = red[4] + red[5] + red[6] + red[7];
+    __syncthreads();
+    return v;
+  };
+  const int* bt = p.b_loc + (int64_t)b * p.b_loc_stride;
+  float m_run = -INFINITY, l_run = 0.f, o = 0.f;
+  for (int n0 = first; n0 <= qpos; n0 += 256) {
+    const int n = n0 + tid;
+    float x = -INFINITY;
+    if (n <= qpos) {
+      const int64_t blk = bt[n / block_size];
+      const uint8_t* kp = p.k_cache + blk * p.kc_block_bytes + (int64_t)(n % block_size) * p.kc_page_bytes +
+                          (int64_t)kvh * p.kc_head_bytes;
+      float acc = 0.f;
+      for (int d = 0; d < head_size; d += 16 / ES) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(kp + d * ES);
+        if constexpr (FP8) {
+          const uint8_t* e = reinterpret_cast<const uint8_t*>(&raw);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc = fmaf(q_s[d + j], fp8_to_f32(e[j]), acc);
+        } else {
+          const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc = fmaf(q_s[d + j], to_f32(e[j]), acc);
+        }
+      }
+      x = acc * p.sm_scale * kscale;
+      if (p.softcap > 0.f) x = p.softcap * tanhf(x / p.softcap);
+      x += slope * (float)(n - qpos);
+    }
+    const float m_new = fmaxf(m_run, block_max(x));
+    const float alpha = __expf(m_run - m_new);   // first chunk: exp(-inf) = 0
+    float e = n <= qpos ? __expf(x - m_new) : 0.f;
+    l_run = l_run * alpha + block_sum(e);
+    m_run = m_new;
+    p_s[tid] = to_f32(from_f32<T>(e));   // probabilities in the value dtype, as the reference's P.to(V.dtype)
+    __syncthreads();
+    o *= alpha;
+    if (tid < head_size) {
+      const int cnt = min(256, qpos - n0 + 1);
+      for (int i = 0; i < cnt; ++i) {
+        const int nn = n0 + i;
+        const int64_t blk = bt[nn / block_size];
+        const uint8_t* vp = p.v_cache + blk * p.vc_block_bytes + (int64_t)(nn % block_size) * p.vc_page_bytes +
+                            (int64_t)kvh * p.vc_head_bytes + (int64_t)tid * ES;
+        const float v = FP8 ? fp8_to_f32(*vp) : to_f32(*reinterpret_cast<const T*>(vp));
+        o = fmaf(p_s[i], v, o);
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < head_size) {
+    const float r = o * vscale / l_run;
+    const int64_t oi = (int64_t)tok * p.o_stride_t + (int64_t)head * p.o_stride_h + tid;
+    if (p.fp8_out_scale) ((uint8_t*)p.o)[oi] = f32_to_fp8(r * (1.0f / *p.fp8_out_scale));
+    else ((T*)p.o)[oi] = from_f32<T>(r);
+  }
+}
+
 extern "C" int vllm_amd_unified_attention(
     void* out, const void* q, const void* k_cache, const void* v_cache, const int* cu_seqlens_q,
     const int* seqused_k, const int* block_table, const float* k_descale, const float* v_descale,
@@ -959,12 +1066,14 @@ extern "C" int vllm_amd_unified_attention(
   VA_REQUIRE(kv_cache_dtype == VLLM_AMD_KV_AUTO || kv_cache_dtype == VLLM_AMD_KV_FP8_E4M3,
              VLLM_AMD_EUNSUPPORTED, "Unsupported FP8 dtype: %d", kv_cache_dtype);
   const int es = kv_cache_dtype == VLLM_AMD_KV_AUTO ? 2 : 1;
-  VA_REQUIRE(head_size >= 8 && head_size <= 128 && head_size % (es == 2 ? 8 : 16) == 0,
+  VA_REQUIRE(head_size >= 8 && head_size <= 256 && head_size % (es == 2 ? 8 : 16) == 0,
              VLLM_AMD_EUNSUPPORTED,
-             "%s: unsupported head size: %d (multiples of 8, of 16 with an fp8 cache, up to 128)",
+             "%s: unsupported head size: %d (multiples of 8, of 16 with an fp8 cache, up to 256)",
              op, head_size);
   VA_REQUIRE(block_size >= 16 && (block_size & (block_size - 1)) == 0, VLLM_AMD_EUNSUPPORTED,
              "%s: unsupported block size: %d (powers of two from 16)", op, block_size);
+  VA_REQUIRE(head_size <= 128 || num_tokens > 0, VLLM_AMD_EINVAL,
+             "%s: head sizes above 128 need num_tokens", op);
   VA_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, VLLM_AMD_EINVAL,
              "%s: num_heads must be a multiple of num_kv_heads", op);
   VA_REQUIRE(es == 2 || (k_descale && v_descale), VLLM_AMD_EINVAL,
@@ -1013,6 +1122,15 @@ extern "C" int vllm_amd_unified_attention(
   p.flat_tokens = num_tokens;
   hipStream_t st = (hipStream_t)stream;
   int rc = VLLM_AMD_OK;
+  if (head_size > 128) {   // the wide-head kernel above
+    const dim3 grid((unsigned)num_tokens, (unsigned)num_heads);
+#define WIDE(T, F) hipLaunchKernelGGL((unified_wide_kernel<T, F>), grid, dim3(256), 0, st, p, num_seqs, head_size, block_size)
+    if (dtype == VLLM_AMD_BF16) { if (es == 2) WIDE(bf16_t, false); else WIDE(bf16_t, true); }
+    else { if (es == 2) WIDE(f16_t, false); else WIDE(f16_t, true); }
+#undef WIDE
+    VA_LAUNCH_CHECK(op);
+    return VLLM_AMD_OK;
+  }
   if (dtype == VLLM_AMD_BF16) {
     if (es == 2) rc = launch_unified<bf16_t, false>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);
     else rc = launch_unified<bf16_t, true>(p, head_size, block_size, max_seqlen_q, max_seqlen_k, num_tokens, num_heads, num_seqs, st);

@@ -84,9 +84,9 @@ class TritonAttentionBackend:
 
     @classmethod
     def get_supported_head_sizes(cls) -> list[int]:
-        # the reference lists [32, 64, 96, 128, 160, 192, 224, 256] (:147-148); the HIP tile
-        # kernel stops at 128
-        return [32, 64, 96, 128]
+        # :147-148.  Up to 128: the MFMA tile / decode kernels; 160 .. 256: the wide-head kernel
+        # (unified_attention only: the prefill + paged-decode path stops at 128)
+        return [32, 64, 96, 128, 160, 192, 224, 256]
 
     @classmethod
     def validate_head_size(cls, head_size: int) -> None:
