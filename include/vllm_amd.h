@@ -408,7 +408,8 @@ int vllm_amd_unified_attention(
 /*                 11 = weight-streaming kernel (M <= 32 only),                 */
 /*                 12, 13 = 32x128 tile (1 / 2 K blocks per barrier)            */
 /*                 14 = 256x256 tile on 4 waves (accumulators in AGPRs),        */
-/*                 15 = 256x256 tile, ring of five half stages (measured, not   */
+/*                 15 = ring of five half stages, 16 = waves 4-7 stage the    */
+/*                 whole tile (14-16: 256x256 variants, measured, not           */
 /*                 used by the heuristic: profiles/r02_gemm_ablation.txt)       */
 /*   "pf_rows":    query rows per workgroup of the prefill kernels (0 = default,    */
 /*                 64 / 128); 1 = unified_attention without GQA packing          */

@@ -112,7 +112,7 @@ def force_kernel():
     _lib.set_tuning("mm_splitk", 0)
 
 
-@pytest.mark.parametrize("kernel", list(range(1, 16)))
+@pytest.mark.parametrize("kernel", list(range(1, 17)))
 @pytest.mark.parametrize("MNK", [(300, 520, 256), (256, 256, 1024), (257, 971, 384), (640, 1288, 2048),
                                  (40, 8, 128 * 3), (5, 264, 512), (32, 1040, 1024)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
@@ -125,7 +125,7 @@ def test_scaled_mm_every_tile_kernel(ops, oracle, force_kernel, kernel, MNK, out
     check(ops, oracle, M, N, K, False, False, out_dtype, bias=False, seed=M + N + kernel)
 
 
-@pytest.mark.parametrize("kernel", list(range(1, 11)) + [12, 13, 14, 15])
+@pytest.mark.parametrize("kernel", list(range(1, 11)) + [12, 13, 14, 15, 16])
 def test_scaled_mm_integer_exact_every_kernel(ops, force_kernel, kernel):
     M, N, K = 512, 768, 640
     g = torch.Generator().manual_seed(kernel)

@@ -327,7 +327,7 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
     int sel = g_mm_kernel;
     const int want_splits = req_splits > 0 ? req_splits : g_mm_splitk;   // 0 = heuristic
     int splits = want_splits > 0 ? want_splits : 1;
-    if (sel == 0 || sel == 11 || sel > 15) {
+    if (sel == 0 || sel == 11 || sel > 16) {
       // Largest tile that still yields ~3/4 of a full wave of workgroups (256 CUs); rows of
       // a tile beyond M are wasted MFMA work, so BM <= 2 M.  With >= 1.5 waves of tiles the
       // variant that fits several workgroups per CU wins, below that the variant that takes

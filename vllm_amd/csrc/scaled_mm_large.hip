@@ -51,6 +51,12 @@ constexpr int LBK = 128;
 #ifdef VA_PROBES
 __device__ unsigned long long g_mm_stamps[4096 * 4];
 __device__ unsigned long long g_mm_stamps_end[4096];
+// per wave of the first 512 workgroups, summed over the K blocks: cycles waiting for the block's
+// LDS-DMA + barrier, from the barrier to the first MFMA's fragments, and for the rest of the block
+__device__ unsigned long long g_mm_phase[512 * 8 * 3];
+#define VA_MM_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#else
+#define VA_MM_T(x) do { } while (0)
 #endif
 
 __device__ __forceinline__ int lswz(int row) {
@@ -124,7 +130,7 @@ __device__ __forceinline__ i32x8 cat8(i32x4 lo, i32x4 hi) {
 }
 
 template <typename out_t, int BM, int BN, int WM, int WN, int NST, int KB, bool VEC_STORE,
-          bool SPLITK>
+          bool SPLITK, int MODE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
     out_t* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ a_scales, const float* __restrict__ b_scales,
@@ -220,6 +226,57 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(bg + w_voff[r]),
           (__attribute__((address_space(3))) void*)(base + A_BYTES + RPR * r * LBK), 16, 0, 0);
+  };
+
+  // load i of a stage (0 .. LOADS-1: the A rounds, then the W rounds), for refills that are
+  // spread over the m-steps of a block instead of being issued back to back
+  auto stage_load_one = [&](auto ic, int stage, int k0) {
+    constexpr int i = decltype(ic)::value;
+    uint8_t* base = lds + stage * STAGE + 8 * wave * LBK;
+    if constexpr (i < A_ROUNDS)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(a + k0 + a_voff[i]),
+          (__attribute__((address_space(3))) void*)(base + RPR * i * LBK), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(b + k0 + w_voff[i - A_ROUNDS]),
+          (__attribute__((address_space(3))) void*)(base + A_BYTES + RPR * (i - A_ROUNDS) * LBK), 16, 0, 0);
+  };
+  // Measured with in-kernel stamps (profiles/r02_gemm_ablation.txt, section 6): a wave that issues
+  // its 8 LDS-DMA loads back to back behind the barrier sits ~600 cycles (waves 4-7: ~1500) in the
+  // vector-memory issue queue -- 8 waves x 8 loads share one address unit, ~35 cycles per load --
+  // before it reaches its first MFMA.  Spreading them, one load behind the MFMAs of each m-step
+  // (-DVA_MM_SPREAD=1), brings the first MFMA forward (238 cycles after the barrier) but every
+  // load then blocks its wave inside the MFMA section (1072 -> 1690 / 2540 cycles): 3166 instead
+  // of 2964 cycles per K block.  The address unit's ~2300 cycles per block are the limit either
+  // way; back-to-back issue stays the default.
+#ifndef VA_MM_SPREAD
+#define VA_MM_SPREAD 0
+#endif
+  constexpr bool SPREAD = VA_MM_SPREAD && KB == 1 && NST == 2 && LOADS <= MT && !R5;
+  // MODE 1 (8 waves, one block per barrier, two stages): the SECOND wave of every SIMD (waves
+  // 4-7) stages the whole tile, two loads behind the MFMAs of each of its m-steps; waves 0-3 issue
+  // no vector-memory instruction at all, so one wave per SIMD always reaches the matrix pipe while
+  // its partner waits at the address unit.  Loader lw = wave - 4 fills rows [32 r + 8 lw, +8) of
+  // round r = 0 .. BM/32-1 of either operand.
+  constexpr bool ASYM = MODE == 1;
+  static_assert(!ASYM || (NW == 8 && KB == 1 && NST == 2 && BM == BN && BM / 32 == MT && !SPLITK), "");
+  // (the source offsets are recomputed per load -- the swizzle does not depend on the round -- so
+  // that the loaders need no second set of offset registers)
+  const int arow0 = 8 * (wave & 3) + srow;
+  const uint32_t asw = (uint32_t)((sslot ^ lswz(arow0)) << 4);
+  auto asym_load = [&](auto ic, int stage, int k0) {   // round r of both operands
+    constexpr int r = decltype(ic)::value;
+    int row = 32 * r + arow0;
+    asm volatile("" : "+v"(row));   // keep hipcc from hoisting the 16 offsets out of the K loop (spills)
+    const int m = min(m0 + row, M - 1), n = min(n0 + row, N - 1);
+    uint8_t* base = lds + stage * STAGE + (32 * r + 8 * (wave & 3)) * LBK;
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(a + k0 + ((uint32_t)m * (uint32_t)lda + asw)),
+        (__attribute__((address_space(3))) void*)base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(b + k0 + ((uint32_t)n * (uint32_t)ldb + asw)),
+        (__attribute__((address_space(3))) void*)(base + A_BYTES), 16, 0, 0);
   };
 
   f32x4 acc[NT][MT];
@@ -325,11 +382,18 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
       });
     }
   }
+  if constexpr (ASYM) {
+    if (wave >= 4) static_for<MT>([&](auto ic) { asym_load(ic, 0, 0); });
+  }
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (!R5 && s < ng) group_load(s, s);
+    if (!R5 && !ASYM && s < ng) group_load(s, s);
   int cur = 0, nxt = NST - 1;   // buffer of group g / of group g + NST - 1
+#ifdef VA_PROBES
+  unsigned long long ph_wait = 0, ph_first = 0, ph_rest = 0;
+#endif
   for (int g = 0; !R5 && g < ng; ++g) {
+    VA_MM_T(ph_t0);
     // own DMA of group g has landed (in the steady state everything but the NST-2 younger
     // groups; near the end fewer are in flight, so drain); then everybody's has, and
     // everybody is done reading the buffer that is restaged next
@@ -340,6 +404,7 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     __builtin_amdgcn_s_barrier();
+    VA_MM_T(ph_t1);
 
     const uint32_t so = cur * (KB * STAGE);
     const uint32_t wa0 = w_addr[0] + so, wa1 = w_addr[1] + so;
@@ -398,11 +463,15 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
     // DMA queue -- no gain, profiles/r02_gemm_ablation.txt.)
     const int fill = nxt;
     const bool late_fill = LATE_FILL && wave >= NW / 2;
+    const bool have_next = g + NST - 1 < ng;
 #if VA_MM_ABLATE != 1
-    if (!late_fill && g + NST - 1 < ng) group_load(fill, g + NST - 1);
+    if (!SPREAD && !ASYM && !late_fill && have_next) group_load(fill, g + NST - 1);
 #endif
     nxt = cur;
     cur = cur + 1 == NST ? 0 : cur + 1;
+#ifdef VA_PROBES
+    unsigned long long ph_t2 = 0;
+#endif
     static_for<KB * MT>([&](auto ic) {
       constexpr int s = decltype(ic)::value;
       constexpr int kb = s / MT, mt = s % MT;
@@ -419,6 +488,9 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
         // step, then W(WA) .. W(NT-1), one in front of each MFMA
         if constexpr (WA < NT) lds_read_frag<kb * STAGE, WA>(wa0, wa1, wl[kb & 1][WA], wh[kb & 1][WA]);
         wait_wa<later + 2 * w_younger<NT>(0)>(wl[kb & 1][0], wh[kb & 1][0], al[s & 1], ah[s & 1]);
+#ifdef VA_PROBES
+        if constexpr (s == 0) ph_t2 = __builtin_amdgcn_s_memtime();
+#endif
         const i32x8 af = cat8(al[s & 1], ah[s & 1]);
         wf[0] = cat8(wl[kb & 1][0], wh[kb & 1][0]);
         acc[0][mt] = mm_mfma(wf[0], af, acc[0][mt]);
@@ -442,6 +514,18 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
         for (int nt = 0; nt < NT; ++nt)
           acc[nt][mt] = mm_mfma(wf[nt], af, acc[nt][mt]);
       }
+#if VA_MM_ABLATE != 1
+      if constexpr (SPREAD && s < LOADS) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (have_next) stage_load_one(ic, fill, (g + NST - 1) * LBK);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (ASYM) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (have_next && wave >= 4) asym_load(ic, fill, (g + NST - 1) * LBK);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
     });
 #if VA_MM_ABLATE != 1
     if constexpr (LATE_FILL) {
@@ -449,7 +533,20 @@ __global__ __launch_bounds__(64 * WM * WN) void scaled_mm_glds_kernel(
       if (late_fill && g + NST - 1 < ng) group_load(fill, g + NST - 1);
     }
 #endif
+#ifdef VA_PROBES
+    {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long ph_t3 = __builtin_amdgcn_s_memtime();
+      ph_wait += ph_t1 - ph_t0; ph_first += ph_t2 - ph_t1; ph_rest += ph_t3 - ph_t2;
+    }
+#endif
   }
+#ifdef VA_PROBES
+  if (!R5 && lane == 0 && blockIdx.x < 512 && wave < 8) {
+    unsigned long long* d = g_mm_phase + ((size_t)blockIdx.x * 8 + wave) * 3;
+    d[0] = ph_wait; d[1] = ph_first; d[2] = ph_rest;
+  }
+#endif
 #ifdef VA_PROBES
   {
     const unsigned long long st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
@@ -669,12 +766,12 @@ static int static_workspace(hipStream_t st, size_t bytes, int tiles, float** ws,
 }
 
 #define GLDS_LAUNCH(VEC, SPLIT, GRID, WS, CTR, S)                                                  \
-  hipLaunchKernelGGL((scaled_mm_glds_kernel<out_t, BM, BN, WM, WN, NST, KB, VEC, SPLIT>),          \
+  hipLaunchKernelGGL((scaled_mm_glds_kernel<out_t, BM, BN, WM, WN, NST, KB, VEC, SPLIT, MODE>),    \
                      dim3(GRID), dim3(64 * WM * WN), 0, g.st, (out_t*)g.out, (const uint8_t*)g.a,  \
                      (const uint8_t*)g.b, g.a_scales, g.b_scales, (const out_t*)g.bias, g.M, g.N,  \
                      g.K, g.lda, g.ldb, g.ldc, g.asn, g.bsn, WS, CTR, S)
 
-template <typename out_t, int BM, int BN, int WM, int WN, int NST, int KB, bool CAN_SPLIT>
+template <typename out_t, int BM, int BN, int WM, int WN, int NST, int KB, bool CAN_SPLIT, int MODE = 0>
 static int launch_glds_t(const GldsArgs& g) {
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   if constexpr (CAN_SPLIT) {
@@ -718,6 +815,7 @@ static int launch_glds_shape(int shape, const GldsArgs& g) {
     case 12: return launch_glds_t<out_t, 32, 128, 1, 4, 4, 1, true>(g);
     case 14: return launch_glds_t<out_t, 256, 256, 2, 2, 2, 1, false>(g);   // 4 waves, 128 x 128 each
     case 15: return launch_glds_t<out_t, 256, 256, 2, 4, 5, 1, false>(g);   // ring of five half stages
+    case 16: return launch_glds_t<out_t, 256, 256, 2, 4, 2, 1, false, 1>(g);   // waves 4-7 stage everything
     default: return launch_glds_t<out_t, 32, 128, 1, 4, 3, 2, true>(g);   // 13
   }
 }
@@ -736,8 +834,8 @@ int launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
                            int out_dtype, bool vec, int splits, int ws_mode, hipStream_t st) {
   // shape = a GldsTile::id of the table in scaled_mm.hip.  Shapes that consume KB blocks per
   // barrier need K % (128 KB) == 0; otherwise the same tile with KB = 1.
-  static const int kb_of[16] = {1, 1, 1, 1, 2, 1, 2, 1, 4, 1, 4, 1, 1, 2, 1, 1};
-  if (shape < 2 || shape > 15 || shape == 11) shape = 3;
+  static const int kb_of[17] = {1, 1, 1, 1, 2, 1, 2, 1, 4, 1, 4, 1, 1, 2, 1, 1, 1};
+  if (shape < 2 || shape > 16 || shape == 11) shape = 3;
   if (K % (LBK * kb_of[shape]) != 0) shape -= 1;
   const GldsArgs g{out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc, asn, bsn, vec, st,
                    splits, ws_mode};
@@ -750,6 +848,9 @@ int launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
 #ifdef VA_PROBES
 extern "C" int vllm_amd_probe_mm_stamps(unsigned long long* dst, int nwg) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(va::g_mm_stamps), (size_t)nwg * 4 * 8) == hipSuccess ? 0 : -3;
+}
+extern "C" int vllm_amd_probe_mm_phase(unsigned long long* dst, int nwg) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(va::g_mm_phase), (size_t)nwg * 8 * 3 * 8) == hipSuccess ? 0 : -3;
 }
 extern "C" int vllm_amd_probe_mm_stamps_end(unsigned long long* dst, int nwg) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(va::g_mm_stamps_end), (size_t)nwg * 8) == hipSuccess ? 0 : -3;
