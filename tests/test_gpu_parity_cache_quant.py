@@ -130,6 +130,52 @@ def test_reshape_and_cache_flash(ops, oracle, dtype, kv, layout, D):
     assert torch.equal(vc_d.cpu().view(torch.uint8), vc_o.view(torch.uint8))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("scales", [(0.37, 0.21), (1e-30, 3.0), (-0.5, 0.125)])
+@pytest.mark.parametrize("op", ["flash", "x_runs", "x_tokens"])
+def test_cache_write_special_values(ops, oracle, dtype, scales, op):
+    """fp8 cache writes of rows that hold +-0, +-inf, NaN, the largest finite values and values
+    whose quotient overflows (tiny scale), next to ordinary ones (the vectorised conversion takes
+    its scalar path for such a vector, wave-uniformly): byte-exact with the oracle, NaN codes up
+    to their sign; also a dense sweep of ordinary values through the vector path."""
+    T, H, D, NB, BS = 64, 4, 128, 16, 16
+    g = torch.Generator().manual_seed(17)
+    key = (torch.randn((T, H, D), generator=g) * 30).to(dtype)
+    value = (torch.randn((T, H, D), generator=g) * 0.3).to(dtype)
+    big = torch.finfo(dtype).max
+    spec = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), float("nan"), big, -big, 1e-7, -448.0, 448.0])
+    for t in range(0, T, 5):      # some rows ordinary, some special
+        key[t, t % H, (7 * t) % (D - 10):(7 * t) % (D - 10) + 10] = spec.to(dtype)
+        value[t, (t + 1) % H, (3 * t) % (D - 10):(3 * t) % (D - 10) + 10] = spec.flip(0).to(dtype)
+    ks, vs = scales
+    slots = torch.arange(T, dtype=torch.int64) + 16 if op == "x_runs" else \
+        torch.randperm(NB * BS, generator=g)[:T].to(torch.int64)
+    if op == "flash":
+        mk = lambda: torch.zeros((NB, BS, H, D), dtype=torch.uint8)
+        fo, fd = oracle.reshape_and_cache_flash, ops.reshape_and_cache_flash
+    else:
+        mk = None
+        fo, fd = oracle.reshape_and_cache, ops.reshape_and_cache
+    if op == "x_runs":           # >= 256 tokens take the run kernel
+        reps = 5
+        key, value = key.repeat(reps, 1, 1), value.repeat(reps, 1, 1)
+        slots = torch.arange(T * reps, dtype=torch.int64) + 16
+        NB = T * reps // BS + 2
+    if mk is None:
+        kc_o = torch.zeros((NB, H, D // 16, BS, 16), dtype=torch.uint8)
+        vc_o = torch.zeros((NB, H, D, BS), dtype=torch.uint8)
+    else:
+        kc_o, vc_o = mk(), mk()
+    kc_d, vc_d = kc_o.clone().cuda(), vc_o.clone().cuda()
+    fo(key, value, kc_o, vc_o, slots, "fp8", ks, vs)
+    fd(key.cuda(), value.cuda(), kc_d, vc_d, slots.cuda(), "fp8", torch.tensor([ks], device="cuda"),
+       torch.tensor([vs], device="cuda"))
+    for got, want in ((kc_d.cpu(), kc_o), (vc_d.cpu(), vc_o)):
+        nan = (want & 0x7f) == 0x7f
+        assert torch.equal(got[~nan], want[~nan])
+        assert ((got[nan] & 0x7f) == 0x7f).all()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_convert_fp8_roundtrip_and_exhaustive(ops, oracle, dtype):
     # every e4m3 code decodes exactly like the oracle's table

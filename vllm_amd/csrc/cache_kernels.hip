@@ -9,7 +9,6 @@
 
 namespace va {
 
-template <typename T, int N> struct alignas(sizeof(T) * N) Vec { T v[N]; };
 
 // ---------------------------------------------------------------------------
 // reshape_and_cache: K -> [blk, h, d/x, off, x]  V -> [blk, h, d, off]
@@ -50,8 +49,7 @@ __global__ void reshape_and_cache_kernel(
                          (int64_t)(xc * X) * block_size + off;
     if constexpr (FP8) {
       Vec<uint8_t, X> kq;
-#pragma unroll
-      for (int j = 0; j < X; ++j) kq.v[j] = f32_to_fp8(kv_quant_prep(kv.v[j], ks));
+      kv_quant_vec(kv, ks, kq);
       *reinterpret_cast<Vec<uint8_t, X>*>(key_cache + kdst) = kq;
 #pragma unroll
       for (int j = 0; j < X; ++j)
@@ -161,8 +159,12 @@ __global__ __launch_bounds__(256) void reshape_and_cache_runs_kernel(
     int64_t blk, off;
     split(slot, blk, off);
     Vec<cache_t, X> kq;
+    if constexpr (FP8) {
+      kv_quant_vec(kreg[u], ks, kq);
+    } else {
 #pragma unroll
-    for (int j = 0; j < X; ++j) kq.v[j] = conv(kreg[u].v[j], ks);
+      for (int j = 0; j < X; ++j) kq.v[j] = conv(kreg[u].v[j], ks);
+    }
     const int hl = c / cph, xc = c % cph;
     *reinterpret_cast<Vec<cache_t, X>*>(key_cache + blk * blk_elems + head_off +
                                          ((int64_t)hl * head_size * block_size) +
@@ -179,8 +181,12 @@ __global__ __launch_bounds__(256) void reshape_and_cache_runs_kernel(
     const int64_t slot = s_slot[i];
     if (slot < 0) continue;
     Vec<cache_t, 8> vq;
+    if constexpr (FP8) {
+      kv_quant_vec(vreg[u], vs, vq);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) vq.v[j] = conv(vreg[u].v[j], vs);
+      for (int j = 0; j < 8; ++j) vq.v[j] = conv(vreg[u].v[j], vs);
+    }
     if (run) {
       *reinterpret_cast<Vec<cache_t, 8>*>(&vt[i][c * 8]) = vq;
     } else {
@@ -303,11 +309,8 @@ __global__ void reshape_and_cache_flash_kernel(
     Vec<scalar_t, VEC> vv = *reinterpret_cast<const Vec<scalar_t, VEC>*>(vrow + src);
     if constexpr (FP8) {
       Vec<uint8_t, VEC> kq, vq;
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        kq.v[j] = f32_to_fp8(kv_quant_prep(kv.v[j], ks));
-        vq.v[j] = f32_to_fp8(kv_quant_prep(vv.v[j], vs));
-      }
+      kv_quant_vec(kv, ks, kq);
+      kv_quant_vec(vv, vs, vq);
       *reinterpret_cast<Vec<uint8_t, VEC>*>(key_cache + dst) = kq;
       *reinterpret_cast<Vec<uint8_t, VEC>*>(value_cache + dst) = vq;
     } else {

@@ -115,6 +115,62 @@ template <typename T> __device__ __forceinline__ float kv_quant_prep(T x, Diviso
   return q;
 }
 
+// N elements at once (cache writes): for bf16 sources the same arithmetic with packed fp32
+// instructions on |x| -- v_pk_mul / v_pk_fma for the division, one integer max over the
+// quotients' bit patterns to find a non-finite one (NaN / inf inputs, overflowing quotients:
+// the whole vector then takes the scalar path above, wave-uniformly), min with 448 (the quotient
+// is >= 0), sign (x ^ scale) put back with one or-instruction, two elements per conversion: ~7
+// VALU instructions per element instead of ~16.  Results are identical bit for bit.
+template <typename T, int N> struct alignas(sizeof(T) * N) Vec { T v[N]; };
+template <typename T, int N>
+__device__ __forceinline__ void kv_quant_vec(const Vec<T, N>& in, Divisor d, Vec<uint8_t, N>& out) {
+  if constexpr (__is_same(T, bf16_t) && N % 4 == 0) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&in);
+    const float as = fabsf(d.s), ay = fabsf(d.y);
+    const uint32_t sm = (__float_as_uint(d.s) >> 16) & 0x8000u;
+    const uint32_t sm2 = sm | (sm << 16);
+    float q[N];
+    uint32_t sg[N / 2], mx = 0;
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+      const uint32_t xw = w[i];
+      sg[i] = (xw & 0x80008000u) ^ sm2;
+      const uint32_t aw = xw & 0x7fff7fffu;
+      const f2 ax = {__uint_as_float(aw << 16), __uint_as_float(aw & 0xffff0000u)};
+      const f2 q0 = ax * (f2){ay, ay};
+      const f2 r = __builtin_elementwise_fma(-q0, (f2){as, as}, ax);
+      const f2 qq = __builtin_elementwise_fma(r, (f2){ay, ay}, q0);
+      q[2 * i] = qq.x;
+      q[2 * i + 1] = qq.y;
+      const uint32_t m2 = __float_as_uint(qq.x) > __float_as_uint(qq.y) ? __float_as_uint(qq.x) : __float_as_uint(qq.y);
+      mx = mx > m2 ? mx : m2;
+    }
+    if (__builtin_expect(__any(mx >= 0x7f800000u), 0)) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) out.v[j] = f32_to_fp8(kv_quant_prep(in.v[j], d));
+      return;
+    }
+    uint32_t* o = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      int word = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = 2 * i + h;
+        const float a = __uint_as_float(__float_as_uint(fminf(q[2 * k], 448.0f)) | (sg[k] << 16));
+        const float b = __uint_as_float(__float_as_uint(fminf(q[2 * k + 1], 448.0f)) | (sg[k] & 0x80000000u));
+        word = h == 0 ? __builtin_amdgcn_cvt_pk_fp8_f32(a, b, word, false)
+                      : __builtin_amdgcn_cvt_pk_fp8_f32(a, b, word, true);
+      }
+      o[i] = (uint32_t)word;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < N; ++j) out.v[j] = f32_to_fp8(kv_quant_prep(in.v[j], d));
+  }
+}
+
 // ---- wave64 reductions ------------------------------------------------------
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
