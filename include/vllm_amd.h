@@ -390,6 +390,39 @@ int vllm_amd_unified_attention(
     float* segm_expsum, int num_segments, int dtype, int kv_cache_dtype, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Peer-to-peer all-reduce over xGMI                         */
+/* ------------------------------------------------------------------------- */
+/* Replaces torch.ops._C_custom_ar.{meta_size, init_custom_ar, register_buffer, all_reduce,
+ * dispose, allocate_shared_buffer_and_handle, open_mem_handle, free_shared_buffer}
+ *   schemas csrc/torch_bindings.cpp:731-754, csrc/custom_all_reduce.cu:13-189,
+ *   kernels csrc/custom_all_reduce.cuh:296-370, one / two stage choice :561-571,
+ *   python vllm/distributed/device_communicators/custom_all_reduce.py:49-305.
+ * meta_ptrs[r] / ptrs[r]: rank r's signal block (vllm_amd_ar_meta_size() bytes, zeroed, followed
+ * by max_size bytes of scratch) / rank r's copy of a registered buffer, as mapped into THIS
+ * process.  all_reduce: out = sum over ranks of their `inp` (f32 / f16 / bf16, fp32 accumulation
+ * in rank order: bit-identical on all ranks), numel * sizeof(dtype) a multiple of 16;
+ * reg_buffer != NULL: inp is first copied into that registered buffer (eager mode), else inp
+ * itself must be registered.  Every wait on a peer is bounded (~1 s): a late or dead peer gives
+ * garbage and vllm_amd_ar_error() != 0, never a hung GPU.  Graph capture: use reg_buffer (the
+ * copy is captured); get_graph_buffer_ipc_meta / register_graph_buffers have no counterpart.
+ * Logic-tested with simulated ranks on one GPU only; off by default. */
+int64_t vllm_amd_ar_meta_size(void);
+int vllm_amd_ar_init(void** handle, void* const* meta_ptrs, int world_size, int rank,
+                     int fully_connected);
+int vllm_amd_ar_register_buffer(void* handle, void* const* ptrs);
+int vllm_amd_ar_all_reduce(void* handle, const void* inp, void* out, int64_t numel, int dtype,
+                           void* reg_buffer, int64_t reg_buffer_bytes, void* stream);
+int vllm_amd_ar_error(void* handle, int* timed_out);
+int vllm_amd_ar_dispose(void* handle);
+/* the only calls of the library that allocate, map or free memory (uncached device memory
+ * + its 64-byte hipIpcMemHandle_t) */
+int vllm_amd_ar_alloc_shared(int64_t bytes, void** ptr, void* ipc_handle);
+int vllm_amd_ar_open_handle(const void* ipc_handle, void** ptr);
+int vllm_amd_ar_close_handle(void* ptr);
+int vllm_amd_ar_free_shared(void* ptr);
+
+
+/* ------------------------------------------------------------------------- */
 /* Tuning knobs (no counterpart in the reference): used by tools/ and bench   */
 /* scripts to A/B kernel variants inside one process.                          */
 /*   "pa_variant": bit 0 = non-temporal K/V loads, bit 1 = two steps of K/V    */

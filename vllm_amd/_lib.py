@@ -65,6 +65,15 @@ SIGNATURES = {
         _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _f, _i, _i, _vp,
         _vp, _vp, _i, _i, _i, _vp],
     "vllm_amd_set_tuning": [C.c_char_p, _i],
+    "vllm_amd_ar_init": [C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i],
+    "vllm_amd_ar_register_buffer": [_vp, C.POINTER(_vp)],
+    "vllm_amd_ar_all_reduce": [_vp, _vp, _vp, _i64, _i, _vp, _i64, _vp],
+    "vllm_amd_ar_error": [_vp, C.POINTER(_i)],
+    "vllm_amd_ar_dispose": [_vp],
+    "vllm_amd_ar_alloc_shared": [_i64, C.POINTER(_vp), _vp],
+    "vllm_amd_ar_open_handle": [_vp, C.POINTER(_vp)],
+    "vllm_amd_ar_close_handle": [_vp],
+    "vllm_amd_ar_free_shared": [_vp],
 }
 
 
@@ -84,6 +93,8 @@ def _load() -> C.CDLL:
     lib.vllm_amd_last_error.restype = C.c_char_p
     lib.vllm_amd_last_error.argtypes = []
     lib.vllm_amd_version.restype = C.c_int
+    lib.vllm_amd_ar_meta_size.restype = C.c_int64
+    lib.vllm_amd_ar_meta_size.argtypes = []
     return lib
 
 

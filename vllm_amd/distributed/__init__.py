@@ -30,12 +30,18 @@ def shard_kv_heads(num_heads: int, num_kv_heads: int, world: int, rank: int):
     return (kv0 * g, kv1 * g), (kv0, kv1)
 
 
-def tensor_model_parallel_all_reduce(x: torch.Tensor, dist=None, group=None) -> torch.Tensor:
-    """communication_op.py:12-14: out-of-place SUM over the TP group."""
+def tensor_model_parallel_all_reduce(x: torch.Tensor, dist=None, group=None, custom_ar=None) -> torch.Tensor:
+    """communication_op.py:12-14: out-of-place SUM over the TP group.  `custom_ar`: a
+    `CustomAllreduce` (custom_all_reduce.py) tried first, as CudaCommunicator.all_reduce does
+    (cuda_communicator.py:93-118); RCCL otherwise."""
     if dist is None:
         import torch.distributed as dist  # type: ignore
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return x
+    if custom_ar is not None:
+        out = custom_ar.custom_all_reduce(x)
+        if out is not None:
+            return out
     out = x.clone()
     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
     return out
