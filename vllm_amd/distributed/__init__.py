@@ -133,3 +133,43 @@ def bench_row_parallel(device, dist, M: int = 256, hidden: int = 8192, iters: in
     res["allreduce_4MiB_us"] = round(t.item() * 1e6, 2)
     res["allreduce_bus_gbps"] = round(2 * (world - 1) / world * nbytes / t.item() / 1e9, 1)
     return res
+
+
+def bench_custom_all_reduce(device, dist, M: int = 256, hidden: int = 8192, iters: int = 20):
+    """The peer-to-peer all-reduce on the configs[3] message ([256, 8192] bf16 = 4 MiB) and on a
+    decode-sized one ([16, 8192] = 256 KiB) next to RCCL, across the ranks of `dist` -- only run
+    when VLLM_AMD_BENCH_CUSTOM_AR=1 (bench.py): this path has never run across GPUs.  The IPC
+    handles travel through a gloo group created here.  Results are checked against RCCL's."""
+    import time
+    from .custom_all_reduce import CustomAllreduce
+    cpu_group = dist.new_group(backend="gloo")
+    ar = CustomAllreduce(cpu_group, device)
+    res = {"disabled": ar.disabled}
+    if ar.disabled:
+        return res
+    try:
+        for rows in (16, M):
+            x = torch.randn((rows, hidden), device=device, dtype=torch.bfloat16)
+            want = x.clone()
+            dist.all_reduce(want)
+            got = ar.custom_all_reduce(x)
+            torch.cuda.synchronize()
+            if ar.timed_out():
+                res["timed_out"] = True     # a barrier gave up: stop here
+                return res
+            res[f"rows{rows}_max_abs_diff_vs_rccl"] = float((got.float() - want.float()).abs().max())
+            for tag, fn in (("custom_us", lambda: ar.custom_all_reduce(x)), ("rccl_us", lambda: dist.all_reduce(x))):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    fn()
+                torch.cuda.synchronize()
+                t = torch.tensor([(time.perf_counter() - t0) / iters], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                res[f"rows{rows}_{tag}"] = round(t.item() * 1e6, 2)
+        res["timed_out"] = ar.timed_out()
+    finally:
+        ar.close()
+    return res
