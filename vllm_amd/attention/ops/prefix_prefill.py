@@ -57,6 +57,11 @@ def context_attention_fwd(q, k, v, o, kv_cache_dtype: str, k_cache, v_cache, b_l
     else:
         assert o.dtype == q.dtype
     # caches: [num_blocks, kv_heads, D/x, block_size, x] and [num_blocks, kv_heads, D, block_size]
+    # x is the engine's 16-byte K vector (PagedAttention.split_kv_cache: x = 16 // element_size); the
+    # Triton kernel takes any x (its test builds x = 8 for every dtype), this kernel does not
+    if k_cache.shape[4] * k_cache.element_size() != 16:
+        raise RuntimeError(f"context_attention_fwd: K cache vector width x={k_cache.shape[4]} with "
+                           f"{k_cache.element_size()}-byte elements; x * element_size must be 16")
     block_size = v_cache.shape[3]
     assert k_cache.stride(4) == 1 and k_cache.stride(3) == k_cache.shape[4] \
         and k_cache.stride(2) == k_cache.shape[3] * k_cache.shape[4]
