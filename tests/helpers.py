@@ -91,7 +91,7 @@ def make_prefill_case(query_lens, ctx_lens, H, KVH, D, BS, dtype, kv_cache_dtype
     perm = torch.randperm(NB, generator=g)
     b_loc = perm[: B * max_blocks].view(B, max_blocks).to(torch.int32)
     fp8 = kv_cache_dtype != "auto"
-    x = 16 if fp8 else 8
+    x = 16 if fp8 else 16 // torch.empty((), dtype=dtype).element_size()   # the engine's 16-byte K vector
     cdt = torch.uint8 if fp8 else dtype
     # stale contents everywhere (incl. NaN patterns) so that masking of tokens >= ctx is tested
     if fp8:

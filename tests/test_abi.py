@@ -175,7 +175,9 @@ def test_validation_errors_of_the_neighbour_ops():
     assert "unsupported head size: 256" in _err(pf(head_size=256))
     assert "unsupported head size: 24" in _err(pf(head_size=24, kv=_lib.KV_FP8_E4M3, qs=192))
     assert "unsupported block size: 8" in _err(pf(block_size=8))
-    assert "float16 or bfloat16" in _err(pf(dtype=_lib.F32))
+    assert "float16, bfloat16 or float32" in _err(pf(dtype=7))
+    assert "float32 queries need num_tokens" in _err(pf(dtype=_lib.F32))
+    assert "unsupported head size: 260" in _err(pf(dtype=_lib.F32, head_size=260))
     assert "Unsupported FP8 dtype" in _err(pf(kv=5))
     assert "multiple of num_kv_heads" in _err(pf(heads=8, kvh=3))
     assert "16-byte aligned" in _err(pf(qs=1021))

@@ -96,6 +96,40 @@ def test_prefill_padded_head_sizes(oracle, head_size, kv):
     torch.testing.assert_close(out.float(), prefill_reference(c), atol=1.5e-3, rtol=0)
 
 
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("head_size", [128, 96, 24])   # test_prefix_prefill.py:23
+@pytest.mark.parametrize("gqa", [1, 4])
+def test_prefill_float32(oracle, kv, head_size, gqa):
+    """float32 queries (test_prefix_prefill.py:513-560 runs its grid with torch.float32): fp32
+    arithmetic end to end; atol 1e-4 is the reference test's own bound for the 'auto' cache (:231)."""
+    if kv == "fp8" and head_size % 16:
+        pytest.skip("fp8 cache layout needs head_size % 16 == 0 (x = 16)")
+    c = make_prefill_case([1, 150, 77, 128], [200, 0, 131, 300], 4, 4 // gqa, head_size, 16,
+                          torch.float32, kv, seed=head_size + gqa, kv_scale=0.02)
+    out = run(c, kv)
+    assert not out.isnan().any()
+    torch.testing.assert_close(out, run_oracle(oracle, c, kv), atol=1e-4, rtol=0)
+    torch.testing.assert_close(out, prefill_reference(c), atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+def test_prefill_float32_window_alibi_skip(oracle, kv):
+    c = make_prefill_case([1, 200, 90], [150, 40, 300], 4, 2, 128, 32, torch.float32, kv, seed=3,
+                          kv_scale=0.02)
+    for window in (16, 128):
+        out = run(c, kv, sliding_window=window)
+        torch.testing.assert_close(out, run_oracle(oracle, c, kv, sliding_window=window), atol=1e-4, rtol=0)
+        torch.testing.assert_close(out, prefill_reference(c, window), atol=1e-4, rtol=0)
+    slopes = torch.tensor([2.0 ** -(i + 1) for i in range(4)])
+    out = run(c, kv, alibi_slopes=slopes.cuda(), sliding_window=64)
+    torch.testing.assert_close(out, run_oracle(oracle, c, kv, alibi_slopes=slopes, sliding_window=64),
+                               atol=1e-4, rtol=0)
+    torch.testing.assert_close(out, prefill_reference(c, 0, slopes), atol=1e-4, rtol=0)
+    out = run(c, kv, skip_decode=True)
+    assert bool((out[0] == 0).all())   # the single-token sequence is left untouched
+    torch.testing.assert_close(out[1:], prefill_reference(c)[1:], atol=1e-4, rtol=0)
+
+
 def test_prefill_skip_decode_and_strides(oracle):
     """skip_decode leaves single-token sequences untouched (:104-105); q / k / v / o may be
     strided views (qkv slices of one projection output)."""

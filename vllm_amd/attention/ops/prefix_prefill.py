@@ -12,7 +12,7 @@ from ... import _lib
 from ..._lib import check, lib
 from ..._torch_ops import _dev, _ptr, _stream
 
-_DT = {torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+_DT = {torch.float16: _lib.F16, torch.bfloat16: _lib.BF16, torch.float32: _lib.F32}
 _FP8 = (torch.uint8, torch.float8_e4m3fn)
 
 

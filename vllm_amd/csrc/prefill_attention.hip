@@ -861,6 +861,137 @@ static void launch_d(const PrefillParams& p, int head_size, int block_size, int 
 
 using namespace va;
 
+// ---------------------------------------------------------------------------------------
+// context_attention_fwd for float32 queries (the reference's test grid has them,
+// tests/kernels/attention/test_prefix_prefill.py:513-560; its Triton kernel then takes the
+// IEEE dot, prefix_prefill.py:760-767): a plain VALU kernel in fp32, one workgroup (256 threads)
+// per (query token, q head) -- chunks of 256 keys, one key per thread for the scores, one
+// output column per thread for P V, online softmax across chunks.  Context keys come from the
+// paged cache (K [blk][kvh][D/x][BS][x] with x = 16 bytes, V [blk][kvh][D][BS]; float32 or
+// fp8 e4m3), the new tokens from the dense k / v.  Masks as the tile kernel's: causal over
+// the new tokens, the window as a -10000 score (:190-192), the ALiBi variant's bias rule
+// (:603-608).  Functional coverage, not a tuned path.
+// ---------------------------------------------------------------------------------------
+template <bool FP8>
+__global__ __launch_bounds__(256) void prefix_f32_kernel(PrefillParams p, int batch, int head_size,
+                                                          int block_size) {
+  const int tok = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+  int lo = 0, hi = batch;   // sequence of this token: the last one with start <= tok
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (p.b_start_loc[mid] <= tok) lo = mid; else hi = mid - 1;
+  }
+  const int b = lo;
+  if (b >= batch || tok >= p.b_start_loc[batch]) return;
+  const int tok0 = p.b_start_loc[b];
+  const int qlen = p.b_start_loc[b + 1] - tok0;
+  const int seq_len = p.b_seq_len[b];
+  const int ctx = seq_len - qlen;
+  if (p.skip_decode && qlen == 1) return;
+  const int m = tok - tok0, qpos = ctx + m;
+  const int kvh = head / (p.num_heads / p.num_kv_heads);
+  constexpr int ES = FP8 ? 1 : 4, X = 16 / ES;
+  const float kscale = FP8 ? *p.k_scale : 1.f, vscale = FP8 ? *p.v_scale : 1.f;
+  const bool alibi = p.alibi_slopes != nullptr;
+  const float slope = alibi ? p.alibi_slopes[head] : 0.f;
+  const int window = alibi ? 0 : p.sliding_window;
+
+  __shared__ float q_s[256];
+  __shared__ float p_s[256];
+  __shared__ float red[8];
+  const float* qp = (const float*)p.q + (int64_t)tok * p.q_stride_t + (int64_t)head * p.q_stride_h;
+  if (tid < head_size) q_s[tid] = qp[tid];
+  __syncthreads();
+  auto block_max = [&](float v) {
+    v = wave_max(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return v;
+  };
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = v;
+    __syncthreads();
+    v = red[4] + red[5] + red[6] + red[7];
+    __syncthreads();
+    return v;
+  };
+  const int* bl = p.b_loc + (int64_t)b * p.b_loc_stride;
+  float m_run = -INFINITY, l_run = 0.f, o = 0.f;
+  for (int n0 = 0; n0 <= qpos; n0 += 256) {
+    const int n = n0 + tid;
+    float x = -INFINITY;
+    if (n <= qpos) {
+      float acc = 0.f;
+      if (n < ctx) {
+        const uint8_t* kp = p.k_cache + (int64_t)bl[n / block_size] * p.kc_block_bytes +
+                            (int64_t)kvh * p.kc_head_bytes + (int64_t)(n % block_size) * 16;
+        for (int d = 0; d < head_size; d += X) {
+          const uint4 raw = *reinterpret_cast<const uint4*>(kp + (int64_t)(d / X) * block_size * 16);
+          if constexpr (FP8) {
+            const uint8_t* e = reinterpret_cast<const uint8_t*>(&raw);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = fmaf(q_s[d + j], fp8_to_f32(e[j]) * kscale, acc);
+          } else {
+            const float* e = reinterpret_cast<const float*>(&raw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = fmaf(q_s[d + j], e[j], acc);
+          }
+        }
+      } else {
+        const float* kp = (const float*)p.k + (int64_t)(tok0 + n - ctx) * p.k_stride_t + (int64_t)kvh * p.k_stride_h;
+        for (int d = 0; d < head_size; d += 4) {
+          const float4 e = *reinterpret_cast<const float4*>(kp + d);
+          acc = fmaf(q_s[d], e.x, acc);
+          acc = fmaf(q_s[d + 1], e.y, acc);
+          acc = fmaf(q_s[d + 2], e.z, acc);
+          acc = fmaf(q_s[d + 3], e.w, acc);
+        }
+      }
+      x = acc * p.sm_scale;
+      if (alibi) {
+        const float bias = (float)(n - qpos) * slope;
+        x = (bias <= 0.f && qpos < seq_len) ? x + bias : -INFINITY;
+      } else if (window > 0 && qpos - n >= window) {
+        x = -10000.0f;
+      }
+    }
+    const float m_new = fmaxf(m_run, block_max(x));
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __expf(m_run - m_use);   // first chunk: exp(-inf) = 0
+    const float e = n <= qpos ? __expf(x - m_use) : 0.f;
+    l_run = l_run * alpha + block_sum(e);
+    m_run = m_new;
+    p_s[tid] = e;
+    __syncthreads();
+    o *= alpha;
+    if (tid < head_size) {
+      const int cnt = min(256, qpos - n0 + 1);
+      for (int i = 0; i < cnt; ++i) {
+        const int nn = n0 + i;
+        float v;
+        if (nn < ctx) {
+          const uint8_t* vp = p.v_cache + (int64_t)bl[nn / block_size] * p.vc_block_bytes +
+                              (int64_t)kvh * p.vc_head_bytes + ((int64_t)tid * block_size + nn % block_size) * ES;
+          v = FP8 ? fp8_to_f32(*vp) * vscale : *reinterpret_cast<const float*>(vp);
+        } else {
+          v = ((const float*)p.v)[(int64_t)(tok0 + nn - ctx) * p.v_stride_t + (int64_t)kvh * p.v_stride_h + tid];
+        }
+        o = fmaf(p_s[i], v, o);
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < head_size) {
+    const float r = l_run > 0.f ? o / l_run : 0.f;
+    const int64_t oi = (int64_t)tok * p.o_stride_t + (int64_t)head * p.o_stride_h + tid;
+    if (p.fp8_out_scale) ((uint8_t*)p.o)[oi] = f32_to_fp8(fmaxf(-448.0f, fminf(r * (1.0f / *p.fp8_out_scale), 448.0f)));
+    else ((float*)p.o)[oi] = r;
+  }
+}
+
 extern "C" int vllm_amd_context_attention_fwd(
     void* o, const void* q, const void* k, const void* v, const void* k_cache, const void* v_cache,
     const int* b_loc, const int* b_start_loc, const int* b_seq_len, const float* k_scale,
@@ -876,10 +1007,57 @@ extern "C" int vllm_amd_context_attention_fwd(
   if (batch == 0 || max_input_len == 0 || num_heads == 0) return VLLM_AMD_OK;
   VA_REQUIRE(o && q && k && v && k_cache && v_cache && b_loc && b_start_loc && b_seq_len,
              VLLM_AMD_EINVAL, "%s: null pointer", op);
-  VA_REQUIRE(dtype == VLLM_AMD_F16 || dtype == VLLM_AMD_BF16, VLLM_AMD_EUNSUPPORTED,
-             "%s: query dtype must be float16 or bfloat16", op);
+  VA_REQUIRE(dtype == VLLM_AMD_F16 || dtype == VLLM_AMD_BF16 || dtype == VLLM_AMD_F32,
+             VLLM_AMD_EUNSUPPORTED, "%s: query dtype must be float16, bfloat16 or float32", op);
   VA_REQUIRE(kv_cache_dtype == VLLM_AMD_KV_AUTO || kv_cache_dtype == VLLM_AMD_KV_FP8_E4M3,
              VLLM_AMD_EUNSUPPORTED, "Unsupported FP8 dtype: %d", kv_cache_dtype);
+  if (dtype == VLLM_AMD_F32) {   // the VALU kernel above
+    VA_REQUIRE(head_size >= 4 && head_size <= 256 &&
+                   head_size % (kv_cache_dtype == VLLM_AMD_KV_AUTO ? 4 : 16) == 0,
+               VLLM_AMD_EUNSUPPORTED,
+               "%s: unsupported head size: %d (float32: multiples of 4, of 16 with an fp8 cache, up to 256)",
+               op, head_size);
+    VA_REQUIRE(block_size > 0, VLLM_AMD_EUNSUPPORTED, "%s: unsupported block size: %d", op, block_size);
+    VA_REQUIRE(num_tokens > 0, VLLM_AMD_EINVAL, "%s: float32 queries need num_tokens", op);
+    VA_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, VLLM_AMD_EINVAL,
+               "%s: num_heads must be a multiple of num_kv_heads", op);
+    VA_REQUIRE(kv_cache_dtype == VLLM_AMD_KV_AUTO || (k_scale && v_scale), VLLM_AMD_EINVAL,
+               "%s: fp8 cache needs k_scale and v_scale", op);
+    VA_REQUIRE(k_stride_t % 4 == 0 && k_stride_h % 4 == 0 && (((uintptr_t)k) & 15) == 0 &&
+                   (((uintptr_t)k_cache) & 15) == 0 && (((uintptr_t)q) & 3) == 0 &&
+                   (((uintptr_t)v) & 3) == 0 && (((uintptr_t)o) & 3) == 0 &&
+                   (((uintptr_t)v_cache) & 3) == 0,
+               VLLM_AMD_EUNSUPPORTED, "%s: k and k_cache must be 16-byte aligned with strides that are multiples of 4", op);
+    const int es32 = kv_cache_dtype == VLLM_AMD_KV_AUTO ? 4 : 1;
+    PrefillParams p;
+    p.o = o; p.q = q; p.k = k; p.v = v;
+    p.k_cache = (const uint8_t*)k_cache; p.v_cache = (const uint8_t*)v_cache;
+    p.b_loc = b_loc; p.b_start_loc = b_start_loc; p.b_seq_len = b_seq_len;
+    p.k_scale = k_scale; p.v_scale = v_scale; p.alibi_slopes = alibi_slopes;
+    p.fp8_out_scale = fp8_out_scale;
+    p.num_heads = num_heads; p.num_kv_heads = num_kv_heads; p.head_size = head_size;
+    p.b_loc_stride = b_loc_stride;
+    p.q_stride_t = q_stride_t; p.q_stride_h = q_stride_h;
+    p.k_stride_t = k_stride_t; p.k_stride_h = k_stride_h;
+    p.v_stride_t = v_stride_t; p.v_stride_h = v_stride_h;
+    p.o_stride_t = o_stride_t; p.o_stride_h = o_stride_h;
+    p.kc_block_bytes = kc_block_stride * es32; p.kc_head_bytes = kc_head_stride * es32;
+    p.vc_block_bytes = vc_block_stride * es32; p.vc_head_bytes = vc_head_stride * es32;
+    p.kc_page_bytes = p.vc_page_bytes = 0;
+    p.sm_scale = sm_scale;
+    p.sliding_window = sliding_window > 0 ? sliding_window : 0;
+    p.skip_decode = skip_decode;
+    p.softcap = 0.f;
+    p.segm_out = p.segm_max = p.segm_sum = nullptr;
+    p.num_segments = p.segm_stride = 1;
+    p.bs_shift = 0;
+    p.flat_batch = batch; p.flat_tokens = num_tokens;
+    const dim3 grid((unsigned)num_tokens, (unsigned)num_heads);
+    if (es32 == 4) hipLaunchKernelGGL((prefix_f32_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, p, batch, head_size, block_size);
+    else hipLaunchKernelGGL((prefix_f32_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, p, batch, head_size, block_size);
+    VA_LAUNCH_CHECK(op);
+    return VLLM_AMD_OK;
+  }
   VA_REQUIRE(head_size >= 8 && head_size <= 128 &&
                  head_size % (kv_cache_dtype == VLLM_AMD_KV_AUTO ? 8 : 16) == 0,
              VLLM_AMD_EUNSUPPORTED,
