@@ -332,7 +332,10 @@ int vllm_amd_swap_blocks(const void* src, void* dst, int64_t block_bytes,
  *                     one-token sequences launch no empty workgroups)
  * Supported here: f16 / bf16 queries, head_size a multiple of 8 (16 with an fp8 cache) up to
  * 128 (padded to a multiple of 32 inside the kernel), block_size 16/32,
- * kv_cache_dtype auto / fp8_e4m3. */
+ * kv_cache_dtype auto / fp8_e4m3.  float32 queries (the reference test's second grid,
+ * tests/kernels/attention/test_prefix_prefill.py:513-560; cache float32 with x = 4, or fp8):
+ * head_size a multiple of 4 (16 with an fp8 cache) up to 256, any block_size, num_tokens
+ * required; computed in fp32 on a plain kernel. */
 int vllm_amd_context_attention_fwd(
     void* o, const void* q, const void* k, const void* v, const void* k_cache,
     const void* v_cache, const int* b_loc, const int* b_start_loc,
