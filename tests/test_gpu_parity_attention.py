@@ -295,3 +295,37 @@ def test_v1_zero_length_sequences(ops, v1_form):
     torch.cuda.synchronize()
     assert not o.isnan().any()
     assert (o[0] == 0).all() and (o[2] == 0).all() and (o[1] != 0).any() and (o[3] != 0).any()
+
+
+@pytest.mark.parametrize("shape", [(64, 32, 8), (200, 8, 2), (256, 3, 3), (40, 16, 8)])
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+def test_v1_longest_first_order(ops, oracle, shape, kv):
+    """Unpartitioned launches of 257..1024 workgroups hand the sequences to the hardware workgroup
+    ids longest first (pa_lpt_wg): a permutation of who computes what, so the output must be
+    bit-identical to the hardware order ("pa_order" = 0) -- with ties, zero lengths, lengths above
+    the max_seq_len argument (keys are clamped), and a batch of equal lengths (identity)."""
+    from vllm_amd import _lib
+    S, H, KVH = shape
+    g = torch.Generator().manual_seed(S + H)
+    lens = torch.randint(1, 400, (S,), generator=g).tolist()
+    lens[3] = lens[7] = lens[S - 1] = 333          # ties
+    lens[5] = 1
+    c = make_attn_case(S, H, KVH, 128, 16, torch.bfloat16, kv, lens, seed=S, kv_scale=1.0 if kv == "auto" else 0.5)
+    run_case(ops, oracle, c, "v1")                 # against the oracle, default order
+    q, kc, vc, bt = (to_dev(c[k]) for k in ("q", "kc", "vc", "bt"))
+    sc = torch.tensor([c["kv_scale"]], device="cuda")
+    zero = list(lens)
+    zero[0] = zero[9] = 0
+    for name, ll, max_len in (("ragged", lens, c["max_len"]), ("clamped keys", lens, 64),
+                              ("zero lengths", zero, c["max_len"]), ("equal", [257] * S, 257)):
+        sl = torch.tensor(ll, dtype=torch.int32, device="cuda")
+        outs = []
+        for order in (1, 0):
+            _lib.set_tuning("pa_order", order)
+            o = torch.full_like(q, float("nan"))
+            ops.paged_attention_v1(o, q, kc, vc, KVH, c["scale"], bt, sl, 16, max_len, None, kv, sc, sc)
+            outs.append(o)
+        _lib.set_tuning("pa_order", 1)
+        torch.cuda.synchronize()
+        assert not outs[0].isnan().any(), name
+        assert torch.equal(outs[0], outs[1]), name

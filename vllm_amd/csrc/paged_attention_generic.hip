@@ -565,6 +565,7 @@ extern "C" int vllm_amd_set_tuning(const char* key, int value) {
   if (strcmp(key, "pa_sp") == 0) { set_pa_sp(value); return VLLM_AMD_OK; }
   if (strcmp(key, "pa_group") == 0) { set_pa_group(value); return VLLM_AMD_OK; }
   if (strcmp(key, "pa_balance") == 0) { set_pa_balance(value); return VLLM_AMD_OK; }
+  if (strcmp(key, "pa_order") == 0) { set_pa_order(value); return VLLM_AMD_OK; }
   if (strcmp(key, "mm_kernel") == 0) { g_mm_kernel = value; return VLLM_AMD_OK; }
   if (strcmp(key, "cache_runs") == 0) { g_cache_runs = value; return VLLM_AMD_OK; }
   if (strcmp(key, "mm_splitk") == 0) { g_mm_splitk = value; return VLLM_AMD_OK; }

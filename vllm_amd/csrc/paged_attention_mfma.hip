@@ -47,9 +47,15 @@ constexpr int kDefaultVariant = 1;   // set from measurements, see DESIGN.md
 __device__ unsigned long long g_pa_stamps[16384 * 4];
 #define VA_STAMP_DECL unsigned long long va_stamp_[4] = {0, 0, 0, 0}
 #define VA_STAMP(i) va_stamp_[i] = __builtin_amdgcn_s_memrealtime()
+#ifdef VA_PROBE_HWID   // stamp 1 = HW_ID (wave / SIMD / CU / SH / SE ids) | XCC_ID << 32: where the workgroup ran
+#define VA_STAMP_HWID() va_stamp_[1] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32)
+#else
+#define VA_STAMP_HWID() do { } while (0)
+#endif
 #define VA_STAMP_FLUSH()                                                                  \
   do {                                                                                    \
     va_stamp_[3] = __builtin_amdgcn_s_memrealtime();                                      \
+    VA_STAMP_HWID();                                                                      \
     if (threadIdx.x == 0)                                                                 \
       for (int i_ = 0; i_ < 4; ++i_)                                                      \
         g_pa_stamps[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 4 + i_] = va_stamp_[i_]; \
@@ -75,6 +81,7 @@ struct PaK {
   // balanced launches (BAL): partial slots, ticket counters, batch size
   float* bal_ws; unsigned* bal_ctr; int num_seqs;
   int window;   // sliding window of the decode token (0 = none): keys [seq_len - window, seq_len)
+  int order;    // > 0: longest-first workgroup order (pa_lpt_wg), = bits of the largest sequence length
 };
 
 // What a workgroup does with one piece of one sequence: tokens [start_tok, end_tok) of `seq`.
@@ -87,6 +94,83 @@ struct PaPiece {
   int first_tok = 0;   // tokens in front of it are masked (sliding window; start_tok is its step, rounded down)
   float* slot; const float* slots; unsigned* ticket; int jf, jl, pre, n_tot, gk;
 };
+
+// Unpartitioned launches of 257 .. 1024 workgroups (paged_attention_v1: no scratch, one workgroup per
+// sequence and kv head): which sequence a HARDWARE workgroup id takes.  Ids i and i + 256 run on
+// the same CU (measured: tools/pa_placement.py, 100 % of 512 workgroups, two per CU), everything is
+// resident at once, and a CU that drew two long sequences of a ragged batch sets the launch time
+// (64 x U[512, 4096] tokens: the CU with 3566 + 3934 tokens exits at 59 us, the one with
+// 1021 + 1525 at 24 us).  A hardware id keeps its (kv head, q-head chunk) = id % groups -- which
+// XCD streams which head does not change -- and takes, among the ids of its group (slot j = id /
+// groups), a sequence by length rank (ties by index): the nf slots whose ids are below 256 take
+// ranks nf-1 .. 0, the later slots ranks nf, nf+1, ...: the CU with the shortest of the first
+// round gets the longest of the rest, and ids past 512, dispatched as CUs free up, come longest
+// first.  Every workgroup derives the same ranking from seq_lens by itself: the lengths
+// sit one per lane (up to 4 registers = 256 sequences), the rank-th largest key is found by a
+// bitwise search with ballots (scalar work), ties by lane order.  A batch of equal lengths
+// (one ballot) keeps the identity order.  Keys are clamped to `bits` bits, so a length above the
+// caller's max_seq_len only perturbs the order, never the bijection.  Returns the logical
+// workgroup id seq * groups + group and the sequence's length.
+__device__ __forceinline__ int pa_lpt_wg(const int* __restrict__ seq_lens, int S, int groups, int bits,
+                                         int lane, int hw, int& seq_len_out) {
+  const int j = hw / groups, grp = hw - j * groups;
+  int nf = (256 - grp + groups - 1) / groups;   // slots of this group with a hardware id below 256
+  nf = nf < S ? nf : S;
+  const int srank = j < nf ? nf - 1 - j : j;
+  const int kmax = (int)((1u << bits) - 1u);
+  int len[4], key[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int idx = 64 * r + lane;
+    len[r] = idx < S ? seq_lens[idx] : 0;
+    key[r] = idx < S ? min(max(len[r], 0), kmax) : -1;
+  }
+  const int k0 = __builtin_amdgcn_readfirstlane(key[0]);
+  bool uniform = true;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) uniform = uniform && __ballot(key[r] == k0 || key[r] < 0) == ~0ull;
+  int seq = j;
+  if (!uniform) {
+    seq = srank;
+    int cand = 0;
+    for (int b = bits - 1; b >= 0; --b) {
+      const int t = cand | (1 << b);
+      int cnt = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cnt += __popcll(__ballot(key[r] >= t));
+      if (cnt > srank) cand = t;
+    }
+    int k = srank;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) k -= __popcll(__ballot(key[r] > cand));
+    int found = -1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      unsigned long long m = __ballot(key[r] == cand);
+      const int c = __popcll(m);
+      if (found < 0) {
+        if (k < c) {
+          int pos = 0;   // the k-th set bit of m
+#pragma unroll
+          for (int w = 32; w >= 1; w >>= 1) {
+            const unsigned long long low = m & ((1ull << w) - 1ull);
+            const int cl = __popcll(low);
+            if (k >= cl) { k -= cl; m >>= w; pos += w; } else { m = low; }
+          }
+          found = 64 * r + pos;
+        } else {
+          k -= c;
+        }
+      }
+    }
+    if (found >= 0) seq = found;
+  }
+  seq = __builtin_amdgcn_readfirstlane(seq);
+  const int rr = seq >> 6;
+  const int v = rr == 0 ? len[0] : rr == 1 ? len[1] : rr == 2 ? len[2] : len[3];
+  seq_len_out = __builtin_amdgcn_readlane(v, seq & 63);
+  return seq * groups + grp;
+}
 
 template <int HEAD_SIZE> constexpr int pa_slot_floats() { return 16 * HEAD_SIZE + 32; }   // O[16][D], m[16], l[16]
 
@@ -535,7 +619,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
     int64_t kv_head_bytes, const float* __restrict__ k_scale_p,
     const float* __restrict__ v_scale_p, int partition_size, int max_parts, int gqa_chunks,
     int slot_stride_arg, int dr_arg, float* __restrict__ bal_ws, unsigned* __restrict__ bal_ctr,
-    int num_seqs, int window) {
+    int num_seqs, int window, int order) {
   VA_STAMP_DECL;
   VA_STAMP(0);
   // (the pointers stay __restrict__ kernel parameters: as members of a by-value struct they lose
@@ -544,7 +628,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
   const PaK<scalar_t> A{out, exp_sums, max_logits, q, k_cache, v_cache, num_heads, num_kv_heads, scale,
                         block_tables, seq_lens, query_start_loc, max_num_blocks_per_seq, alibi_slopes,
                         q_stride, kv_block_bytes, kv_head_bytes, k_scale_p, v_scale_p, partition_size,
-                        max_parts, gqa_chunks, slot_stride_arg, dr_arg, bal_ws, bal_ctr, num_seqs, window};
+                        max_parts, gqa_chunks, slot_stride_arg, dr_arg, bal_ws, bal_ctr, num_seqs, window, order};
   constexpr int STEP_TOK = (FP8 ? 4 : 2) * 16;
   constexpr int P_BYTES = 16 * kPRowBytes;
   constexpr int MERGE_BYTES = NW * HEAD_SIZE * 16 * 4 + NW * 16 * 8;
@@ -562,9 +646,12 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
     const int nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
     wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
+  const int groups = A.gqa_chunks * A.num_kv_heads;
+  int lpt_len = -1;
+  if constexpr (!BAL)
+    if (A.order > 0) wg = pa_lpt_wg(A.seq_lens, A.num_seqs, groups, A.order, lane, wg, lpt_len);
   const int chunk = wg % A.gqa_chunks;
   const int kvh = (wg / A.gqa_chunks) % A.num_kv_heads;
-  const int groups = A.gqa_chunks * A.num_kv_heads;
   PaPiece P;
   if constexpr (!BAL) {
     const int seq = wg / groups;
@@ -575,7 +662,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
       if (A.query_start_loc[seq + 1] - A.query_start_loc[seq] != 1) return;
       P.qrow = A.query_start_loc[seq];
     }
-    P.seq_len = A.seq_lens[seq];
+    P.seq_len = A.order > 0 ? lpt_len : A.seq_lens[seq];
     const bool partitioned = A.partition_size > 0;
     P.start_tok = partitioned ? part * A.partition_size : 0;
     if (partitioned && P.start_tok >= P.seq_len) return;
@@ -714,8 +801,11 @@ void set_pa_group(int v) { g_pa_group = v; }
       (A).num_kv_heads, (A).scale, (A).block_tables, (A).seq_lens, (A).query_start_loc,            \
       (A).max_num_blocks_per_seq, (A).alibi_slopes, (A).q_stride, (A).kv_block_bytes,              \
       (A).kv_head_bytes, (A).k_scale_p, (A).v_scale_p, (A).partition_size, (A).max_parts,          \
-      (A).gqa_chunks, (A).slot_stride, (A).dr_arg, (A).bal_ws, (A).bal_ctr, (A).num_seqs, (A).window
+      (A).gqa_chunks, (A).slot_stride, (A).dr_arg, (A).bal_ws, (A).bal_ctr, (A).num_seqs, (A).window, \
+      (A).order
 
+static int g_pa_order = 1;   // tuning "pa_order": 0 = hardware order for unpartitioned launches
+void set_pa_order(int v) { g_pa_order = v; }
 static int g_pa_balance = 0;   // tuning "pa_balance": 1 = balanced v1 launches whenever possible, else never
 void set_pa_balance(int v) { g_pa_balance = v; }
 
@@ -744,6 +834,15 @@ static int launch_mfma_v(const PagedAttnParams& p) {
   A.partition_size = p.partition_size * sp; A.max_parts = p.max_num_partitions;
   A.gqa_chunks = chunks; A.slot_stride = group ? -sp : sp; A.dr_arg = p.head_size;
   A.bal_ws = nullptr; A.bal_ctr = nullptr; A.num_seqs = p.num_seqs; A.window = p.window;
+  // longest-first order (pa_lpt_wg): unpartitioned launches whose workgroups are all resident or
+  // nearly so; "pa_order" = 0 turns it off
+  A.order = 0;
+  if (!part && !p.query_start_loc && !group && g_pa_order != 0 && grid.x > 256 && grid.x <= 1024 &&
+      p.num_seqs <= 256 && p.max_seq_len > 0) {
+    int bits = 1;
+    while (bits < 30 && (p.max_seq_len >> bits) != 0) ++bits;
+    A.order = bits;
+  }
 
   // Balanced v1 launch (opt-in, "pa_balance" = 1): paged_attention_v1 has no scratch arguments,
   // so with one workgroup per (sequence, kv head) a skewed batch waits for its longest sequence.
