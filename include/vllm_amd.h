@@ -437,6 +437,9 @@ int vllm_amd_ar_free_shared(void* ptr);
 /*   "pa_balance": 1 = paged_attention_v1 cuts the concatenated sequences into equal    */
 /*                 ranges, two workgroups per CU, and merges shared sequences through   */
 /*                 the registered workspace (pays on skewed batches only; default 0)    */
+/*   "pa_order":   0 = unpartitioned decode launches keep the hardware's workgroup     */
+/*                 order (default 1: sequences handed out longest first, the two       */
+/*                 workgroups of a CU paired long + short; same output bits)          */
 /*   "mm_kernel":  scaled_mm kernel for M > 32: 0 = heuristic, 1 = register-   */
 /*                 staged 128x128 tile, 2..10 = direct-to-LDS tile shapes       */
 /*                 (256x256, 128x128, 128x64, 64x64, 64x32; even ids 4..10      */
