@@ -324,3 +324,37 @@ def test_unified_mixed_batch_with_caller_segments_c_abi(oracle, fp8):
     torch.cuda.synchronize()
     assert not out.isnan().any()
     torch.testing.assert_close(out.cpu().float(), ref.float(), atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("shape", [(64, 16, 8), (200, 4, 2)])
+def test_unified_decode_longest_first_order(oracle, fp8, shape):
+    """Unsplit decode launches of 257..1024 workgroups hand the sequences out longest first
+    (pa_lpt_wg, common.cuh): the output equals the oracle's and is bit-identical to the hardware
+    order ("pa_order" = 0), with ties among the lengths and a mixed batch (non-decode sequences
+    leave their workgroups at once)."""
+    from vllm_amd import _lib
+    from vllm_amd.attention.ops import unified_attention
+    S, H, KVH = shape
+    g = torch.Generator().manual_seed(S)
+    kvl = torch.randint(1, 400, (S,), generator=g).tolist()
+    kvl[2] = kvl[11] = kvl[S - 1] = 123
+    for mixed in (False, True):
+        sl = [(1, n) for n in kvl]
+        if mixed:
+            sl[4] = (3, kvl[4] + 3)
+            sl[20] = (40, 40)
+        c = make_unified_case(sl, H, KVH, 128, 16, torch.bfloat16, fp8=fp8, seed=S + mixed, kv_scale=0.5)
+        run(oracle, c, torch.bfloat16, fp8=fp8)
+        kd = c["scale"].cuda() if fp8 else None
+        outs = []
+        for order in (1, 0):
+            _lib.set_tuning("pa_order", order)
+            out = torch.zeros(c["q"].shape, dtype=torch.bfloat16, device="cuda")
+            unified_attention(c["q"].cuda(), c["k"].cuda(), c["v"].cuda(), out, c["cu_seqlens_q"].cuda(),
+                              c["max_seqlen_q"], c["seqused_k"].cuda(), c["max_seqlen_k"], 128 ** -0.5,
+                              True, (-1, -1), c["block_table"].cuda(), 0.0, None, kd, kd)
+            outs.append(out)
+        _lib.set_tuning("pa_order", 1)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1])

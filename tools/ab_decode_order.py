@@ -20,3 +20,22 @@ for name, sl_ in (("uniform", sl), ("ragged", lens.to(dev))):
             _, ev = bench.time_gpu(fn, 50, 5)
             print(f"{name} order={order}: {ev / 50 * 1e6:.2f} us", flush=True)
 _lib.set_tuning("pa_order", 1)
+
+# the flash-layout decode kernel of unified_attention (V1 engine), same batch
+from vllm_amd.attention.ops import unified_attention
+NBK = S * (ctx // BS)
+kf = torch.randint(0, 120, (NBK, BS, KVH, D), device=dev, dtype=torch.uint8)
+vf = torch.randint(0, 120, (NBK, BS, KVH, D), device=dev, dtype=torch.uint8)
+btu = torch.randperm(NBK, device=dev).to(torch.int32).view(S, ctx // BS)
+cu = torch.arange(S + 1, device=dev, dtype=torch.int32)
+qb = q.to(torch.bfloat16) if q.dtype != torch.bfloat16 else q
+o = torch.empty_like(qb)
+for name, sl_ in (("unified uniform", sl), ("unified ragged", lens.to(dev))):
+    mx = int(sl_.max())
+    fn = lambda: unified_attention(qb, kf, vf, o, cu, 1, sl_, mx, D ** -0.5, True, (-1, -1), btu, 0.0, None, one, one)
+    for rep in range(2):
+        for order in (0, 1):
+            _lib.set_tuning("pa_order", order)
+            _, ev = bench.time_gpu(fn, 50, 5)
+            print(f"{name} order={order}: {ev / 50 * 1e6:.2f} us", flush=True)
+_lib.set_tuning("pa_order", 1)

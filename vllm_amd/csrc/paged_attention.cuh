@@ -45,6 +45,7 @@ void set_pa_sp(int v);
 void set_pa_group(int v);
 void set_pa_balance(int v);
 void set_pa_order(int v);
+bool pa_order_enabled();
 // Split-K merge of partitions (v2 / rocm).
 int paged_attention_reduce(const PagedAttnParams& p);
 

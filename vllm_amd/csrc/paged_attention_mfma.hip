@@ -95,83 +95,7 @@ struct PaPiece {
   float* slot; const float* slots; unsigned* ticket; int jf, jl, pre, n_tot, gk;
 };
 
-// Unpartitioned launches of 257 .. 1024 workgroups (paged_attention_v1: no scratch, one workgroup per
-// sequence and kv head): which sequence a HARDWARE workgroup id takes.  Ids i and i + 256 run on
-// the same CU (measured: tools/pa_placement.py, 100 % of 512 workgroups, two per CU), everything is
-// resident at once, and a CU that drew two long sequences of a ragged batch sets the launch time
-// (64 x U[512, 4096] tokens: the CU with 3566 + 3934 tokens exits at 59 us, the one with
-// 1021 + 1525 at 24 us).  A hardware id keeps its (kv head, q-head chunk) = id % groups -- which
-// XCD streams which head does not change -- and takes, among the ids of its group (slot j = id /
-// groups), a sequence by length rank (ties by index): the nf slots whose ids are below 256 take
-// ranks nf-1 .. 0, the later slots ranks nf, nf+1, ...: the CU with the shortest of the first
-// round gets the longest of the rest, and ids past 512, dispatched as CUs free up, come longest
-// first.  Every workgroup derives the same ranking from seq_lens by itself: the lengths
-// sit one per lane (up to 4 registers = 256 sequences), the rank-th largest key is found by a
-// bitwise search with ballots (scalar work), ties by lane order.  A batch of equal lengths
-// (one ballot) keeps the identity order.  Keys are clamped to `bits` bits, so a length above the
-// caller's max_seq_len only perturbs the order, never the bijection.  Returns the logical
-// workgroup id seq * groups + group and the sequence's length.
-__device__ __forceinline__ int pa_lpt_wg(const int* __restrict__ seq_lens, int S, int groups, int bits,
-                                         int lane, int hw, int& seq_len_out) {
-  const int j = hw / groups, grp = hw - j * groups;
-  int nf = (256 - grp + groups - 1) / groups;   // slots of this group with a hardware id below 256
-  nf = nf < S ? nf : S;
-  const int srank = j < nf ? nf - 1 - j : j;
-  const int kmax = (int)((1u << bits) - 1u);
-  int len[4], key[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int idx = 64 * r + lane;
-    len[r] = idx < S ? seq_lens[idx] : 0;
-    key[r] = idx < S ? min(max(len[r], 0), kmax) : -1;
-  }
-  const int k0 = __builtin_amdgcn_readfirstlane(key[0]);
-  bool uniform = true;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) uniform = uniform && __ballot(key[r] == k0 || key[r] < 0) == ~0ull;
-  int seq = j;
-  if (!uniform) {
-    seq = srank;
-    int cand = 0;
-    for (int b = bits - 1; b >= 0; --b) {
-      const int t = cand | (1 << b);
-      int cnt = 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cnt += __popcll(__ballot(key[r] >= t));
-      if (cnt > srank) cand = t;
-    }
-    int k = srank;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) k -= __popcll(__ballot(key[r] > cand));
-    int found = -1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      unsigned long long m = __ballot(key[r] == cand);
-      const int c = __popcll(m);
-      if (found < 0) {
-        if (k < c) {
-          int pos = 0;   // the k-th set bit of m
-#pragma unroll
-          for (int w = 32; w >= 1; w >>= 1) {
-            const unsigned long long low = m & ((1ull << w) - 1ull);
-            const int cl = __popcll(low);
-            if (k >= cl) { k -= cl; m >>= w; pos += w; } else { m = low; }
-          }
-          found = 64 * r + pos;
-        } else {
-          k -= c;
-        }
-      }
-    }
-    if (found >= 0) seq = found;
-  }
-  seq = __builtin_amdgcn_readfirstlane(seq);
-  const int rr = seq >> 6;
-  const int v = rr == 0 ? len[0] : rr == 1 ? len[1] : rr == 2 ? len[2] : len[3];
-  seq_len_out = __builtin_amdgcn_readlane(v, seq & 63);
-  return seq * groups + grp;
-}
-
+// (pa_lpt_wg, the longest-first workgroup order of unpartitioned launches: common.cuh)
 template <int HEAD_SIZE> constexpr int pa_slot_floats() { return 16 * HEAD_SIZE + 32; }   // O[16][D], m[16], l[16]
 
 // VARIANT bit 0: non-temporal K/V loads
@@ -806,6 +730,7 @@ void set_pa_group(int v) { g_pa_group = v; }
 
 static int g_pa_order = 1;   // tuning "pa_order": 0 = hardware order for unpartitioned launches
 void set_pa_order(int v) { g_pa_order = v; }
+bool pa_order_enabled() { return g_pa_order != 0; }
 static int g_pa_balance = 0;   // tuning "pa_balance": 1 = balanced v1 launches whenever possible, else never
 void set_pa_balance(int v) { g_pa_balance = v; }
 

@@ -774,6 +774,7 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
     u.kc_block_bytes = p.kc_block_bytes; u.kc_slot_bytes = p.kc_page_bytes; u.kc_head_bytes = p.kc_head_bytes;
     u.vc_block_bytes = p.vc_block_bytes; u.vc_slot_bytes = p.vc_page_bytes; u.vc_head_bytes = p.vc_head_bytes;
     u.sm_scale = p.sm_scale; u.softcap = p.softcap; u.window = p.sliding_window;
+    u.max_seq_len = max_k;
     u.segm_out = p.segm_out; u.segm_max = p.segm_max; u.segm_sum = p.segm_sum;
     u.segm_stride = p.segm_stride;
     u.dtype = std::is_same<T, f16_t>::value ? VLLM_AMD_F16 : VLLM_AMD_BF16;

@@ -14,6 +14,7 @@ struct UniDecodeParams {
   int64_t kc_block_bytes, kc_slot_bytes, kc_head_bytes, vc_block_bytes, vc_slot_bytes, vc_head_bytes;
   float sm_scale, softcap;
   int window;            // 0 = none; key n visible iff seq_len - 1 - n < window
+  int max_seq_len = 0;   // upper bound of seq_lens if the caller knows one (0 = unknown): sizes the keys of the longest-first order
   // split over the keys: segment s takes the 64-token tiles [s tps, (s+1) tps), tps =
   // cdiv(cdiv(seq_len, 64), num_segments) -- the partition unified_reduce_kernel assumes
   float* segm_out; float* segm_max; float* segm_sum;
@@ -22,6 +23,8 @@ struct UniDecodeParams {
   bool fp8;              // e4m3 cache
   hipStream_t stream;
 };
+
+bool pa_order_enabled();   // tuning "pa_order" (paged_attention_mfma.hip)
 
 // true when every query of the launch may take the decode kernel (the caller has checked
 // max_seqlen_q == 1); false WITHOUT touching memory otherwise

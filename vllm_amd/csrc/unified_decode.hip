@@ -54,7 +54,7 @@ __device__ __forceinline__ typename DwVec<N>::type nt_load(const uint8_t* p) {
 }
 
 template <typename T, bool FP8, int D, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodeParams p, int sub_shift, int xcd_group) {
+__global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodeParams p, int sub_shift, int xcd_group, int order) {
   constexpr int ES = FP8 ? 1 : 2;             // cache element bytes
   constexpr int TILES = FP8 ? 4 : 2;          // 16-token tiles per step
   constexpr int STEP_TOK = TILES * 16;
@@ -81,6 +81,10 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   // chunk fastest: the chunks re-read the same K / V, through L2 when they run together
   const int Gall = p.num_heads / p.num_kv_heads;
   const int chunks = (Gall + 15) >> 4;
+  // unsplit launches of 257 .. 1024 workgroups: sequences handed out longest first, the two
+  // workgroups of a CU paired long + short (pa_lpt_wg, common.cuh; same output bits)
+  int lpt_len = -1;
+  if (order > 0) wg = pa_lpt_wg(p.seq_lens, p.num_seqs, chunks * p.num_kv_heads, order, lane, wg, lpt_len);
   const int chunk = wg % chunks, kvh = (wg / chunks) % p.num_kv_heads, seq = wg / (chunks * p.num_kv_heads);
   const int seg = blockIdx.y;
   const int G = min(16, Gall - 16 * chunk);   // q heads of this workgroup
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   const int dr = p.head_size;
 
   // (all three loads before the first branch: one memory round trip, not two)
-  const int seq_len = p.seq_lens[seq];
+  const int seq_len = order > 0 ? lpt_len : p.seq_lens[seq];
   const int qtok = p.cu_seqlens_q[seq], qend = p.cu_seqlens_q[seq + 1];
   if (qend - qtok != 1) return;   // not a decode token: the tile kernel's (or nobody's) business
   const int ctx = seq_len - 1;                       // position of the query
@@ -472,8 +476,15 @@ int launch(const UniDecodeParams& p) {
   while ((16 << sub_shift) < p.block_size) ++sub_shift;
   const int chunks = (p.num_heads / p.num_kv_heads + 15) / 16;
   const dim3 grid((unsigned)(p.num_seqs * p.num_kv_heads * chunks), (unsigned)(p.num_segments > 1 ? p.num_segments : 1));
+  const int xcd_group = g_uni_decode == 2 ? 1 : g_uni_decode == 3 ? 0 : (grid.x * grid.y >= 1024 ? 1 : 0);
+  int order = 0;   // key bits of the longest-first order; tuning "pa_order" = 0 turns it off
+  if (pa_order_enabled() && grid.y == 1 && !xcd_group && grid.x > 256 && grid.x <= 1024 && p.num_seqs <= 256) {
+    const int ml = p.max_seq_len > 0 ? p.max_seq_len : (1 << 29);
+    order = 1;
+    while (order < 30 && (ml >> order) != 0) ++order;
+  }
   hipLaunchKernelGGL((ua_decode_kernel<T, FP8, D, NW>), grid, dim3(NW * 64), 0, p.stream, p, sub_shift,
-                     g_uni_decode == 2 ? 1 : g_uni_decode == 3 ? 0 : (grid.x * grid.y >= 1024 ? 1 : 0));
+                     xcd_group, order);
   VA_LAUNCH_CHECK("unified_attention decode launch");
   if (p.num_segments > 1) {
     hipLaunchKernelGGL((ua_decode_reduce_kernel<T, D>), dim3((unsigned)((p.num_seqs * p.num_heads + 3) / 4)),
