@@ -297,7 +297,8 @@ def test_v1_zero_length_sequences(ops, v1_form):
     assert (o[0] == 0).all() and (o[2] == 0).all() and (o[1] != 0).any() and (o[3] != 0).any()
 
 
-@pytest.mark.parametrize("shape", [(64, 32, 8), (200, 8, 2), (256, 3, 3), (40, 16, 8)])
+@pytest.mark.parametrize("shape", [(64, 32, 8), (200, 8, 2), (256, 3, 3), (40, 16, 8),
+                                   (256, 8, 8), (128, 16, 8), (136, 8, 8), (250, 8, 8)])   # the last four: XCD-grouped launches
 @pytest.mark.parametrize("kv", ["auto", "fp8"])
 def test_v1_longest_first_order(ops, oracle, shape, kv):
     """Unpartitioned launches of 257..1024 workgroups hand the sequences to the hardware workgroup

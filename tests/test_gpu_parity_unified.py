@@ -327,7 +327,7 @@ def test_unified_mixed_batch_with_caller_segments_c_abi(oracle, fp8):
 
 
 @pytest.mark.parametrize("fp8", [False, True])
-@pytest.mark.parametrize("shape", [(64, 16, 8), (200, 4, 2)])
+@pytest.mark.parametrize("shape", [(64, 16, 8), (200, 4, 2), (256, 8, 8)])   # the last: XCD-grouped
 def test_unified_decode_longest_first_order(oracle, fp8, shape):
     """Unsplit decode launches of 257..1024 workgroups hand the sequences out longest first
     (pa_lpt_wg, common.cuh): the output equals the oracle's and is bit-identical to the hardware

@@ -39,3 +39,20 @@ for name, sl_ in (("unified uniform", sl), ("unified ragged", lens.to(dev))):
             _, ev = bench.time_gpu(fn, 50, 5)
             print(f"{name} order={order}: {ev / 50 * 1e6:.2f} us", flush=True)
 _lib.set_tuning("pa_order", 1)
+
+# 256 sequences (2048 workgroups, XCD-grouped launch, several rounds)
+del kf, vf, caches
+S2 = 256
+q2, caches2, bt2, sl2, one2 = bench.make_attention_inputs(S2, ctx, H, KVH, D, BS, True, dev, n_caches=1)
+lens2 = torch.randint(512, ctx + 1, (S2,), generator=g).to(torch.int32)
+for name, sl_ in (("S256 uniform", sl2), ("S256 ragged", lens2.to(dev))):
+    mx = int(sl_.max())
+    kc, vc = caches2[0]
+    fn = lambda: PagedAttention.forward_decode(q2, kc, vc, bt2, sl_, mx, "fp8", KVH, D ** -0.5, None, one2, one2)
+    nbytes = int(sl_.sum()) * KVH * D * 2
+    for rep in range(2):
+        for order in (0, 1):
+            _lib.set_tuning("pa_order", order)
+            _, ev = bench.time_gpu(fn, 20, 3)
+            print(f"{name} order={order}: {ev / 20 * 1e6:.2f} us  {nbytes / (ev / 20) / 1e12:.2f} TB/s", flush=True)
+_lib.set_tuning("pa_order", 1)

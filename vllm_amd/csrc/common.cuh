@@ -199,12 +199,26 @@ __device__ __forceinline__ float wave_sum(float v) {
 // (one ballot) keeps the identity order.  Keys are clamped to `bits` bits, so a length above the
 // caller's max_seq_len only perturbs the order, never the bijection.  Returns the logical
 // workgroup id seq * groups + group and the sequence's length.
+// xcd_grouped (launches of >= 1024 workgroups whose hardware ids are remapped so that XCD x = id % 8
+// serves the sequences [x S/8, (x+1) S/8) with all their groups; S % 8 == 0): the workgroups are
+// handed out as CUs free up, so the order is plain longest first, dealt to the XCDs snake-wise
+// (position t of XCD x takes rank 8 t + x, or 8 t + 7 - x for odd t) so that every XCD gets the
+// same share of long sequences; the tail of the launch is then made of the shortest sequences.
 __device__ __forceinline__ int pa_lpt_wg(const int* __restrict__ seq_lens, int S, int groups, int bits,
-                                         int lane, int hw, int& seq_len_out) {
-  const int j = hw / groups, grp = hw - j * groups;
-  int nf = (256 - grp + groups - 1) / groups;   // slots of this group with a hardware id below 256
-  nf = nf < S ? nf : S;
-  const int srank = j < nf ? nf - 1 - j : j;
+                                         int lane, int hw, int& seq_len_out, bool xcd_grouped = false) {
+  int j, grp, srank;
+  if (xcd_grouped) {
+    const int xcd = hw & 7, idx = hw >> 3, t = idx / groups;
+    grp = idx - t * groups;
+    j = xcd * (S >> 3) + t;                       // the remap's own sequence (kept for equal lengths)
+    srank = 8 * t + ((t & 1) ? 7 - xcd : xcd);
+  } else {
+    j = hw / groups;
+    grp = hw - j * groups;
+    int nf = (256 - grp + groups - 1) / groups;   // slots of this group with a hardware id below 256
+    nf = nf < S ? nf : S;
+    srank = j < nf ? nf - 1 - j : j;
+  }
   const int kmax = (int)((1u << bits) - 1u);
   int len[4], key[4];
 #pragma unroll

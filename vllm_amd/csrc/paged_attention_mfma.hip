@@ -566,14 +566,14 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
   // Large launches: consecutive hardware ids go to different XCDs (id % 8); remapped so that the
   // kv heads of a sequence -- adjacent pages of the same blocks -- stream through one XCD's L2
   // (256 sequences x 8 kv heads x 4096 fp8: 330.6 -> 324.6 us; nothing at 512 workgroups)
-  if (slot_stride < 0) {
+  const int groups = A.gqa_chunks * A.num_kv_heads;
+  int lpt_len = -1;
+  if (!BAL && A.order > 0) {
+    wg = pa_lpt_wg(A.seq_lens, A.num_seqs, groups, A.order, lane, wg, lpt_len, slot_stride < 0);
+  } else if (slot_stride < 0) {
     const int nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
     wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
-  const int groups = A.gqa_chunks * A.num_kv_heads;
-  int lpt_len = -1;
-  if constexpr (!BAL)
-    if (A.order > 0) wg = pa_lpt_wg(A.seq_lens, A.num_seqs, groups, A.order, lane, wg, lpt_len);
   const int chunk = wg % A.gqa_chunks;
   const int kvh = (wg / A.gqa_chunks) % A.num_kv_heads;
   PaPiece P;
@@ -759,11 +759,12 @@ static int launch_mfma_v(const PagedAttnParams& p) {
   A.partition_size = p.partition_size * sp; A.max_parts = p.max_num_partitions;
   A.gqa_chunks = chunks; A.slot_stride = group ? -sp : sp; A.dr_arg = p.head_size;
   A.bal_ws = nullptr; A.bal_ctr = nullptr; A.num_seqs = p.num_seqs; A.window = p.window;
-  // longest-first order (pa_lpt_wg): unpartitioned launches whose workgroups are all resident or
-  // nearly so; "pa_order" = 0 turns it off
+  // longest-first order (pa_lpt_wg): unpartitioned launches over <= 256 sequences, of 257..1024
+  // workgroups (resident or nearly so: long + short paired per CU) or XCD-grouped (several rounds:
+  // plain longest first); "pa_order" = 0 turns it off
   A.order = 0;
-  if (!part && !p.query_start_loc && !group && g_pa_order != 0 && grid.x > 256 && grid.x <= 1024 &&
-      p.num_seqs <= 256 && p.max_seq_len > 0) {
+  if (!part && !p.query_start_loc && g_pa_order != 0 && grid.x > 256 && p.num_seqs <= 256 && p.max_seq_len > 0 &&
+      (group ? p.num_seqs % 8 == 0 : grid.x <= 1024)) {
     int bits = 1;
     while (bits < 30 && (p.max_seq_len >> bits) != 0) ++bits;
     A.order = bits;

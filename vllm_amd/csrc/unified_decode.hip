@@ -73,7 +73,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   // token rows -- are fetched through ONE XCD's L2 at about the same time (256 x 4096 fp8:
   // 5.6 -> 5.8 TB/s, 512 x 2048: 5.55 -> 5.94; no gain below two rounds of workgroups).
   int wg = blockIdx.x;
-  if (xcd_group) {
+  if (xcd_group && order <= 0) {
     const int nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
     wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   // unsplit launches of 257 .. 1024 workgroups: sequences handed out longest first, the two
   // workgroups of a CU paired long + short (pa_lpt_wg, common.cuh; same output bits)
   int lpt_len = -1;
-  if (order > 0) wg = pa_lpt_wg(p.seq_lens, p.num_seqs, chunks * p.num_kv_heads, order, lane, wg, lpt_len);
+  if (order > 0) wg = pa_lpt_wg(p.seq_lens, p.num_seqs, chunks * p.num_kv_heads, order, lane, wg, lpt_len, xcd_group != 0);
   const int chunk = wg % chunks, kvh = (wg / chunks) % p.num_kv_heads, seq = wg / (chunks * p.num_kv_heads);
   const int seg = blockIdx.y;
   const int G = min(16, Gall - 16 * chunk);   // q heads of this workgroup
@@ -478,7 +478,8 @@ int launch(const UniDecodeParams& p) {
   const dim3 grid((unsigned)(p.num_seqs * p.num_kv_heads * chunks), (unsigned)(p.num_segments > 1 ? p.num_segments : 1));
   const int xcd_group = g_uni_decode == 2 ? 1 : g_uni_decode == 3 ? 0 : (grid.x * grid.y >= 1024 ? 1 : 0);
   int order = 0;   // key bits of the longest-first order; tuning "pa_order" = 0 turns it off
-  if (pa_order_enabled() && grid.y == 1 && !xcd_group && grid.x > 256 && grid.x <= 1024 && p.num_seqs <= 256) {
+  if (pa_order_enabled() && grid.y == 1 && grid.x > 256 && p.num_seqs <= 256 &&
+      (xcd_group ? p.num_seqs % 8 == 0 : grid.x <= 1024)) {
     const int ml = p.max_seq_len > 0 ? p.max_seq_len : (1 << 29);
     order = 1;
     while (order < 30 && (ml >> order) != 0) ++order;
