@@ -313,6 +313,9 @@ def test_v1_longest_first_order(ops, oracle, shape, kv):
     lens[5] = 1
     c = make_attn_case(S, H, KVH, 128, 16, torch.bfloat16, kv, lens, seed=S, kv_scale=1.0 if kv == "auto" else 0.5)
     run_case(ops, oracle, c, "v1")                 # against the oracle, default order
+    if H // KVH <= 16 and S <= 136:                # v2 / rocm with one super-partition per sequence: same order
+        run_case(ops, oracle, c, "v2")
+        run_case(ops, oracle, c, "rocm")
     q, kc, vc, bt = (to_dev(c[k]) for k in ("q", "kc", "vc", "bt"))
     sc = torch.tensor([c["kv_scale"]], device="cuda")
     zero = list(lens)

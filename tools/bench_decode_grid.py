@@ -18,6 +18,7 @@ ap.add_argument("--bs", type=int, default=16)
 ap.add_argument("--sp", default="0", help="comma list of pa_sp tuning values (0 = heuristic)")
 ap.add_argument("--op", default="auto", help="auto (forward_decode) | rocm (paged_attention_rocm)")
 ap.add_argument("--ragged", action="store_true", help="sequence lengths uniform in [ctx/8, ctx]")
+ap.add_argument("--order", default="1", help="comma list of pa_order tuning values (1 = default)")
 a = ap.parse_args()
 H, KVH = (int(x) for x in a.heads.split(","))
 D, BS = 128, a.bs
@@ -39,11 +40,13 @@ for S in (int(x) for x in a.batches.split(",")):
         es = 1 if fp8 else 2
         toks = int(sl.sum().item())
         nbytes = 2 * toks * KVH * D * es + 2 * 2 * S * H * D
-        for sp in (int(x) for x in a.sp.split(",")):
+        for sp, order in ((int(x), int(y)) for x in a.sp.split(",") for y in a.order.split(",")):
             _lib.set_tuning("pa_sp", sp)
+            _lib.set_tuning("pa_order", order)
             t = bench.time_gpu_graph(fn, 10)
-            print(f"S={S:4d} ctx={ctx:6d} {a.kv} H={H}/{KVH} bs={BS} {a.op} sp={sp}{' ragged' if a.ragged else ''}: "
+            print(f"S={S:4d} ctx={ctx:6d} {a.kv} H={H}/{KVH} bs={BS} {a.op} sp={sp} order={order}{' ragged' if a.ragged else ''}: "
                   f"{t * 1e6:9.1f} us {nbytes / t / 1e9:8.1f} GB/s ({nbytes / t / 8e12 * 100:5.1f}% of HBM peak)",
                   flush=True)
         _lib.set_tuning("pa_sp", 0)
+        _lib.set_tuning("pa_order", 1)
         del q, caches, kc, vc

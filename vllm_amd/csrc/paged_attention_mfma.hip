@@ -579,7 +579,11 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
   PaPiece P;
   if constexpr (!BAL) {
     const int seq = wg / groups;
-    const int part = blockIdx.y;
+    // partitioned launches, order < 0: the LAST super-partitions go first.  The hardware hands out
+    // blockIdx.y in rising order; the high partitions exist only for the longest sequences of a
+    // ragged batch, so in rising order the launch ends on a few workgroups streaming alone, while
+    // partition 0 -- the last to go in falling order -- exists for every sequence
+    const int part = A.order < 0 ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
     P.seq = seq;
     P.qrow = seq;
     if (A.query_start_loc) {
@@ -759,11 +763,12 @@ static int launch_mfma_v(const PagedAttnParams& p) {
   A.partition_size = p.partition_size * sp; A.max_parts = p.max_num_partitions;
   A.gqa_chunks = chunks; A.slot_stride = group ? -sp : sp; A.dr_arg = p.head_size;
   A.bal_ws = nullptr; A.bal_ctr = nullptr; A.num_seqs = p.num_seqs; A.window = p.window;
-  // longest-first order (pa_lpt_wg): unpartitioned launches over <= 256 sequences, of 257..1024
+  // longest-first order (pa_lpt_wg): launches of one piece per sequence (v1, or v2 / rocm when one
+  // super-partition covers max_seq_len) over <= 256 sequences, of 257..1024
   // workgroups (resident or nearly so: long + short paired per CU) or XCD-grouped (several rounds:
   // plain longest first); "pa_order" = 0 turns it off
-  A.order = 0;
-  if (!part && !p.query_start_loc && g_pa_order != 0 && grid.x > 256 && p.num_seqs <= 256 && p.max_seq_len > 0 &&
+  A.order = (part && g_pa_order != 0) ? -1 : 0;
+  if ((!part || grid.y == 1) && !p.query_start_loc && g_pa_order != 0 && grid.x > 256 && p.num_seqs <= 256 && p.max_seq_len > 0 &&
       (group ? p.num_seqs % 8 == 0 : grid.x <= 1024)) {
     int bits = 1;
     while (bits < 30 && (p.max_seq_len >> bits) != 0) ++bits;
