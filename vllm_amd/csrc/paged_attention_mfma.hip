@@ -770,8 +770,11 @@ static int launch_mfma_v(const PagedAttnParams& p) {
   A.order = (part && g_pa_order != 0) ? -1 : 0;
   if ((!part || grid.y == 1) && !p.query_start_loc && g_pa_order != 0 && grid.x > 256 && p.num_seqs <= 256 && p.max_seq_len > 0 &&
       (group ? p.num_seqs % 8 == 0 : grid.x <= 1024)) {
+    // keys = lengths clamped to `bits` bits; with a sliding window a workgroup streams at most
+    // `window` keys, so longer sequences rank (about) equal
+    const int ml = (p.window > 0 && p.window < p.max_seq_len) ? p.window : p.max_seq_len;
     int bits = 1;
-    while (bits < 30 && (p.max_seq_len >> bits) != 0) ++bits;
+    while (bits < 30 && (ml >> bits) != 0) ++bits;
     A.order = bits;
   }
 

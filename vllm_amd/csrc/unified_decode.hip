@@ -480,7 +480,8 @@ int launch(const UniDecodeParams& p) {
   int order = 0;   // key bits of the longest-first order; tuning "pa_order" = 0 turns it off
   if (pa_order_enabled() && grid.y == 1 && grid.x > 256 && p.num_seqs <= 256 &&
       (xcd_group ? p.num_seqs % 8 == 0 : grid.x <= 1024)) {
-    const int ml = p.max_seq_len > 0 ? p.max_seq_len : (1 << 29);
+    int ml = p.max_seq_len > 0 ? p.max_seq_len : (1 << 29);
+    if (p.window > 0 && p.window < ml) ml = p.window;   // a workgroup streams at most `window` keys
     order = 1;
     while (order < 30 && (ml >> order) != 0) ++order;
   }
