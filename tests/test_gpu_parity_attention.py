@@ -316,6 +316,39 @@ def test_v1_longest_first_order(ops, oracle, shape, kv):
     if H // KVH <= 16 and S <= 136:                # v2 / rocm with one super-partition per sequence: same order
         run_case(ops, oracle, c, "v2")
         run_case(ops, oracle, c, "rocm")
+        # rocm op with query_start_loc (a mixed batch: rows 2 and 6 are not decode tokens and must
+        # stay untouched), order on / off
+        from helpers import to_dev as _d
+        qsl = torch.arange(S + 1, dtype=torch.int32)
+        qsl[3:] += 4
+        qsl[7:] += 9
+        Tq = int(qsl[-1])
+        qbig = torch.zeros((Tq, H, 128), dtype=torch.bfloat16)
+        rows = qsl[:-1].long()
+        qbig[rows] = c["q"]
+        P = (c["max_len"] + 255) // 256
+        res = []
+        for order in (1, 0):
+            _lib.set_tuning("pa_order", order)
+            o = torch.full((Tq, H, 128), 7.0, dtype=torch.bfloat16, device="cuda")
+            es = torch.zeros((S, H, P), dtype=torch.float32, device="cuda")
+            tmp = torch.zeros((S, H, P, 128), dtype=torch.bfloat16, device="cuda")
+            ks = torch.tensor([c["kv_scale"]], device="cuda")
+            ops.paged_attention_rocm(o, es, torch.zeros_like(es), tmp, _d(qbig), _d(c["kc"]), _d(c["vc"]), KVH,
+                                     c["scale"], _d(c["bt"]), _d(c["sl"]), _d(qsl), 16, c["max_len"], None, kv, ks, ks)
+            res.append(o)
+        _lib.set_tuning("pa_order", 1)
+        torch.cuda.synchronize()
+        assert torch.equal(res[0], res[1])
+        keep = torch.ones(Tq, dtype=torch.bool)
+        keep[rows] = False
+        keep[rows[2]] = keep[rows[6]] = True     # sequences 2 and 6 have 5 and 10 query tokens: skipped
+        assert bool((res[0].cpu()[keep] == 7.0).all())
+        dec = [i for i in range(S) if i not in (2, 6)]
+        ref = torch.zeros_like(c["q"])
+        oracle.paged_attention_v1(ref, c["q"], c["kc"], c["vc"], KVH, c["scale"], c["bt"], c["sl"], 16,
+                                  c["max_len"], None, kv, c["kv_scale"], c["kv_scale"])
+        torch.testing.assert_close(res[0].cpu()[rows[dec]].float(), ref[dec].float(), **TOL["auto" if kv == "auto" else "fp8"])
     q, kc, vc, bt = (to_dev(c[k]) for k in ("q", "kc", "vc", "bt"))
     sc = torch.tensor([c["kv_scale"]], device="cuda")
     zero = list(lens)

@@ -346,6 +346,8 @@ def test_unified_decode_longest_first_order(oracle, fp8, shape):
             sl[20] = (40, 40)
         c = make_unified_case(sl, H, KVH, 128, 16, torch.bfloat16, fp8=fp8, seed=S + mixed, kv_scale=0.5)
         run(oracle, c, torch.bfloat16, fp8=fp8)
+        if not mixed:
+            run(oracle, c, torch.bfloat16, fp8=fp8, window=100)   # keys clamp at the window
         kd = c["scale"].cuda() if fp8 else None
         outs = []
         for order in (1, 0):

@@ -768,7 +768,7 @@ static int launch_mfma_v(const PagedAttnParams& p) {
   // workgroups (resident or nearly so: long + short paired per CU) or XCD-grouped (several rounds:
   // plain longest first); "pa_order" = 0 turns it off
   A.order = (part && g_pa_order != 0) ? -1 : 0;
-  if ((!part || grid.y == 1) && !p.query_start_loc && g_pa_order != 0 && grid.x > 256 && p.num_seqs <= 256 && p.max_seq_len > 0 &&
+  if ((!part || grid.y == 1) && g_pa_order != 0 && grid.x > 256 && p.num_seqs <= 256 && p.max_seq_len > 0 &&
       (group ? p.num_seqs % 8 == 0 : grid.x <= 1024)) {
     // keys = lengths clamped to `bits` bits; with a sliding window a workgroup streams at most
     // `window` keys, so longer sequences rank (about) equal
