@@ -298,7 +298,8 @@ def test_v1_zero_length_sequences(ops, v1_form):
 
 
 @pytest.mark.parametrize("shape", [(64, 32, 8), (200, 8, 2), (256, 3, 3), (40, 16, 8),
-                                   (256, 8, 8), (128, 16, 8), (136, 8, 8), (250, 8, 8)])   # the last four: XCD-grouped launches
+                                   (256, 8, 8), (128, 16, 8), (136, 8, 8), (250, 8, 8),   # XCD-grouped launches
+                                   (512, 4, 2), (1000, 2, 2), (1024, 1, 1), (1032, 2, 2)])   # 8 / 16 registers of lengths; above the limit
 @pytest.mark.parametrize("kv", ["auto", "fp8"])
 def test_v1_longest_first_order(ops, oracle, shape, kv):
     """Unpartitioned launches of 257..1024 workgroups hand the sequences to the hardware workgroup

@@ -194,7 +194,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ranks nf-1 .. 0, the later slots ranks nf, nf+1, ...: the CU with the shortest of the first
 // round gets the longest of the rest, and ids past 512, dispatched as CUs free up, come longest
 // first.  Every workgroup derives the same ranking from seq_lens by itself: the lengths
-// sit one per lane (up to 4 registers = 256 sequences), the rank-th largest key is found by a
+// sit one per lane (4, 8 or 16 registers: up to 1024 sequences), the rank-th largest key is found by a
 // bitwise search with ballots (scalar work), ties by lane order.  A batch of equal lengths
 // (one ballot) keeps the identity order.  Keys are clamped to `bits` bits, so a length above the
 // caller's max_seq_len only perturbs the order, never the bijection.  Returns the logical
@@ -204,6 +204,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // handed out as CUs free up, so the order is plain longest first, dealt to the XCDs snake-wise
 // (position t of XCD x takes rank 8 t + x, or 8 t + 7 - x for odd t) so that every XCD gets the
 // same share of long sequences; the tail of the launch is then made of the shortest sequences.
+constexpr int kLptMaxSeqs = 1024;   // 16 registers of 64 lengths
+template <int NR = 4>   // NR registers of 64 lengths: S <= 64 NR
 __device__ __forceinline__ int pa_lpt_wg(const int* __restrict__ seq_lens, int S, int groups, int bits,
                                          int lane, int hw, int& seq_len_out, bool xcd_grouped = false) {
   int j, grp, srank;
@@ -220,9 +222,9 @@ __device__ __forceinline__ int pa_lpt_wg(const int* __restrict__ seq_lens, int S
     srank = j < nf ? nf - 1 - j : j;
   }
   const int kmax = (int)((1u << bits) - 1u);
-  int len[4], key[4];
+  int len[NR], key[NR];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < NR; ++r) {
     const int idx = 64 * r + lane;
     len[r] = idx < S ? seq_lens[idx] : 0;
     key[r] = idx < S ? min(max(len[r], 0), kmax) : -1;
@@ -230,7 +232,7 @@ __device__ __forceinline__ int pa_lpt_wg(const int* __restrict__ seq_lens, int S
   const int k0 = __builtin_amdgcn_readfirstlane(key[0]);
   bool uniform = true;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) uniform = uniform && __ballot(key[r] == k0 || key[r] < 0) == ~0ull;
+  for (int r = 0; r < NR; ++r) uniform = uniform && __ballot(key[r] == k0 || key[r] < 0) == ~0ull;
   int seq = j;
   if (!uniform) {
     seq = srank;
@@ -239,15 +241,15 @@ __device__ __forceinline__ int pa_lpt_wg(const int* __restrict__ seq_lens, int S
       const int t = cand | (1 << b);
       int cnt = 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cnt += __popcll(__ballot(key[r] >= t));
+      for (int r = 0; r < NR; ++r) cnt += __popcll(__ballot(key[r] >= t));
       if (cnt > srank) cand = t;
     }
     int k = srank;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) k -= __popcll(__ballot(key[r] > cand));
+    for (int r = 0; r < NR; ++r) k -= __popcll(__ballot(key[r] > cand));
     int found = -1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NR; ++r) {
       unsigned long long m = __ballot(key[r] == cand);
       const int c = __popcll(m);
       if (found < 0) {
@@ -269,7 +271,9 @@ __device__ __forceinline__ int pa_lpt_wg(const int* __restrict__ seq_lens, int S
   }
   seq = __builtin_amdgcn_readfirstlane(seq);
   const int rr = seq >> 6;
-  const int v = rr == 0 ? len[0] : rr == 1 ? len[1] : rr == 2 ? len[2] : len[3];
+  int v = len[0];
+#pragma unroll
+  for (int r = 1; r < NR; ++r) v = rr == r ? len[r] : v;
   seq_len_out = __builtin_amdgcn_readlane(v, seq & 63);
   return seq * groups + grp;
 }

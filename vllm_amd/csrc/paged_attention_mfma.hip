@@ -569,7 +569,10 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
   const int groups = A.gqa_chunks * A.num_kv_heads;
   int lpt_len = -1;
   if (!BAL && A.order > 0) {
-    wg = pa_lpt_wg(A.seq_lens, A.num_seqs, groups, A.order, lane, wg, lpt_len, slot_stride < 0);
+    const bool xg = slot_stride < 0;
+    wg = A.num_seqs <= 256   ? pa_lpt_wg<4>(A.seq_lens, A.num_seqs, groups, A.order, lane, wg, lpt_len, xg)
+         : A.num_seqs <= 512 ? pa_lpt_wg<8>(A.seq_lens, A.num_seqs, groups, A.order, lane, wg, lpt_len, xg)
+                             : pa_lpt_wg<16>(A.seq_lens, A.num_seqs, groups, A.order, lane, wg, lpt_len, xg);
   } else if (slot_stride < 0) {
     const int nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
     wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
@@ -764,11 +767,11 @@ static int launch_mfma_v(const PagedAttnParams& p) {
   A.gqa_chunks = chunks; A.slot_stride = group ? -sp : sp; A.dr_arg = p.head_size;
   A.bal_ws = nullptr; A.bal_ctr = nullptr; A.num_seqs = p.num_seqs; A.window = p.window;
   // longest-first order (pa_lpt_wg): launches of one piece per sequence (v1, or v2 / rocm when one
-  // super-partition covers max_seq_len) over <= 256 sequences, of 257..1024
+  // super-partition covers max_seq_len) over <= 1024 sequences, of 257..1024
   // workgroups (resident or nearly so: long + short paired per CU) or XCD-grouped (several rounds:
   // plain longest first); "pa_order" = 0 turns it off
   A.order = (part && g_pa_order != 0) ? -1 : 0;
-  if ((!part || grid.y == 1) && g_pa_order != 0 && grid.x > 256 && p.num_seqs <= 256 && p.max_seq_len > 0 &&
+  if ((!part || grid.y == 1) && g_pa_order != 0 && grid.x > 256 && p.num_seqs <= kLptMaxSeqs && p.max_seq_len > 0 &&
       (group ? p.num_seqs % 8 == 0 : grid.x <= 1024)) {
     // keys = lengths clamped to `bits` bits; with a sliding window a workgroup streams at most
     // `window` keys, so longer sequences rank (about) equal

@@ -84,7 +84,13 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   // unsplit launches of 257 .. 1024 workgroups: sequences handed out longest first, the two
   // workgroups of a CU paired long + short (pa_lpt_wg, common.cuh; same output bits)
   int lpt_len = -1;
-  if (order > 0) wg = pa_lpt_wg(p.seq_lens, p.num_seqs, chunks * p.num_kv_heads, order, lane, wg, lpt_len, xcd_group != 0);
+  if (order > 0) {
+    const int groups = chunks * p.num_kv_heads;
+    const bool xg = xcd_group != 0;
+    wg = p.num_seqs <= 256   ? pa_lpt_wg<4>(p.seq_lens, p.num_seqs, groups, order, lane, wg, lpt_len, xg)
+         : p.num_seqs <= 512 ? pa_lpt_wg<8>(p.seq_lens, p.num_seqs, groups, order, lane, wg, lpt_len, xg)
+                             : pa_lpt_wg<16>(p.seq_lens, p.num_seqs, groups, order, lane, wg, lpt_len, xg);
+  }
   const int chunk = wg % chunks, kvh = (wg / chunks) % p.num_kv_heads, seq = wg / (chunks * p.num_kv_heads);
   const int seg = blockIdx.y;
   const int G = min(16, Gall - 16 * chunk);   // q heads of this workgroup
@@ -478,7 +484,7 @@ int launch(const UniDecodeParams& p) {
   const dim3 grid((unsigned)(p.num_seqs * p.num_kv_heads * chunks), (unsigned)(p.num_segments > 1 ? p.num_segments : 1));
   const int xcd_group = g_uni_decode == 2 ? 1 : g_uni_decode == 3 ? 0 : (grid.x * grid.y >= 1024 ? 1 : 0);
   int order = 0;   // key bits of the longest-first order; tuning "pa_order" = 0 turns it off
-  if (pa_order_enabled() && grid.y == 1 && grid.x > 256 && p.num_seqs <= 256 &&
+  if (pa_order_enabled() && grid.y == 1 && grid.x > 256 && p.num_seqs <= kLptMaxSeqs &&
       (xcd_group ? p.num_seqs % 8 == 0 : grid.x <= 1024)) {
     int ml = p.max_seq_len > 0 ? p.max_seq_len : (1 << 29);
     if (p.window > 0 && p.window < ml) ml = p.window;   // a workgroup streams at most `window` keys
