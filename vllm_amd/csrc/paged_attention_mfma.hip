@@ -856,16 +856,38 @@ int paged_attention_mfma(const PagedAttnParams& p0) {
   p.sp_parts = 1;
   if (p.partition_size > 0) {
     const int chunks = ceil_div(p.num_heads / p.num_kv_heads, 16);
-    const int64_t total = (int64_t)p.num_seqs * p.num_kv_heads * chunks * p.max_num_partitions;
-    // Uniform batches want one round of 2 workgroups per CU (512); real batches are ragged and
-    // a workgroup per (sequence, head) then waits for the longest sequence, so aim at ~2048
-    // workgroups -- the hardware hands them out as others finish -- but keep >= 2048 tokens per
-    // workgroup while that still fills one round (tools/bench_decode_grid.py: ragged 64 x
-    // [2k, 16k] tokens 244 -> 216 us, uniform 64 x 16k 339 -> 344 us).
-    const int64_t sp_fill = (total + 511) / 512, sp_bal = (total + 2047) / 2048;
-    const int64_t sp_min = p.partition_size >= 2048 ? 1 : 2048 / p.partition_size;
-    int64_t sp = sp_fill < sp_min ? sp_fill : sp_min;
-    if (sp < sp_bal) sp = sp_bal;
+    // The chip holds 512 of these workgroups (two per CU) and hands further ones out as others
+    // finish; the host does not know the batch's lengths (seq_lens live on the device).
+    const int64_t base = (int64_t)p.num_seqs * p.num_kv_heads * chunks;
+    const int64_t P = p.max_num_partitions;
+    int64_t sp;
+    if (base < 512) {
+      // Fewer (sequence, head) pairs than workgroup slots: the sequences must be cut to fill the
+      // chip, and real batches are ragged, so aim at ~2048 workgroups of >= 2048 tokens -- the
+      // hardware hands them out as others finish (ragged 16 x U[8k, 64k] tokens: 215 us, against
+      // 239 us with the 512 longest pieces that a uniform batch would like best).
+      const int64_t total = base * P;
+      const int64_t sp_fill = (total + 511) / 512, sp_bal = (total + 2047) / 2048;
+      const int64_t sp_min = p.partition_size >= 2048 ? 1 : 2048 / p.partition_size;
+      sp = sp_fill < sp_min ? sp_fill : sp_min;
+      if (sp < sp_bal) sp = sp_bal;
+    } else {
+      // Enough pairs to fill the chip: few long pieces stream best (256 x 16k tokens: one piece per
+      // sequence 81.3 % of peak, sp 16 80.3 %, sp 8 78.5 %, sp 4 76.0 %) and a ragged batch is
+      // balanced by the longest-first order of one-piece launches (pa_lpt_wg; 64 x U[2k, 16k]:
+      // 2048-token pieces 218 us, one piece 209 us; 64 x U[8k, 64k]: 755 -> 725 us).  What is left is
+      // the quantisation into rounds of 512 workgroups: with all lengths at max_seq_len a launch of
+      // `pieces` per pair costs ceil(base pieces / 512) rounds of (sp partition_size + ~256 tokens
+      // of prologue and merge); take the cheapest, the longest pieces within 3 %, none below 2048
+      // tokens.  profiles/r02_decode_order.txt §7.
+      sp = P;
+      double best = 1e300;
+      for (int64_t c = P; c >= 1 && c * p.partition_size >= 2048; --c) {
+        const int64_t pieces = (P + c - 1) / c, rounds = (base * pieces + 511) / 512;
+        const double cost = (double)rounds * (double)(c * p.partition_size + 256);
+        if (cost < best * 0.97) { best = cost; sp = c; }
+      }
+    }
     if (g_pa_sp > 0) sp = g_pa_sp;
     if (sp < 1) sp = 1;
     if (sp > p.max_num_partitions) sp = p.max_num_partitions;
