@@ -570,7 +570,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
   int lpt_len = -1;
   if (!BAL && A.order > 0) {
     const bool xg = slot_stride < 0;
-    wg = A.num_seqs <= 256   ? pa_lpt_wg<4>(A.seq_lens, A.num_seqs, groups, A.order, lane, wg, lpt_len, xg)
+    wg = A.num_seqs <= 64    ? pa_lpt_wg<1>(A.seq_lens, A.num_seqs, groups, A.order, lane, wg, lpt_len, xg)
+         : A.num_seqs <= 256 ? pa_lpt_wg<4>(A.seq_lens, A.num_seqs, groups, A.order, lane, wg, lpt_len, xg)
          : A.num_seqs <= 512 ? pa_lpt_wg<8>(A.seq_lens, A.num_seqs, groups, A.order, lane, wg, lpt_len, xg)
                              : pa_lpt_wg<16>(A.seq_lens, A.num_seqs, groups, A.order, lane, wg, lpt_len, xg);
   } else if (slot_stride < 0) {

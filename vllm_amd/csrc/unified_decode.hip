@@ -87,7 +87,8 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   if (order > 0) {
     const int groups = chunks * p.num_kv_heads;
     const bool xg = xcd_group != 0;
-    wg = p.num_seqs <= 256   ? pa_lpt_wg<4>(p.seq_lens, p.num_seqs, groups, order, lane, wg, lpt_len, xg)
+    wg = p.num_seqs <= 64    ? pa_lpt_wg<1>(p.seq_lens, p.num_seqs, groups, order, lane, wg, lpt_len, xg)
+         : p.num_seqs <= 256 ? pa_lpt_wg<4>(p.seq_lens, p.num_seqs, groups, order, lane, wg, lpt_len, xg)
          : p.num_seqs <= 512 ? pa_lpt_wg<8>(p.seq_lens, p.num_seqs, groups, order, lane, wg, lpt_len, xg)
                              : pa_lpt_wg<16>(p.seq_lens, p.num_seqs, groups, order, lane, wg, lpt_len, xg);
   }
