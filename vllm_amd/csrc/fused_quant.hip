@@ -71,13 +71,15 @@ __device__ __forceinline__ float take_x(T in, T* res_slot, bool has_res) {
 // the wave); a lane
 // holds CH chunks of 8 elements and issues all its loads before the first use.
 // MODE_QUANT is dynamic_per_token_scaled_fp8_quant (no norm, no weight).
-template <typename T, int MODE, int W, int CH>
-__global__ __launch_bounds__(ROW_THREADS) void row_quant_vec_kernel(
+// NWV = waves per workgroup (4; 8 for the norm modes on rows above 4096 elements, all on one row:
+// two chunks per lane at 8192 like the 4096-wide rows, instead of four at lower occupancy)
+template <typename T, int MODE, int W, int CH, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void row_quant_vec_kernel(
     uint8_t* __restrict__ out, const T* __restrict__ in, int64_t in_stride, T* __restrict__ residual,
     const T* __restrict__ weight, const float* __restrict__ scale_p, float* __restrict__ scales,
     const float* __restrict__ scale_ub, float eps, int hidden, int64_t num_tokens) {
-  constexpr int RPB = 4 / W;   // rows per workgroup
-  __shared__ float red[2][4];
+  constexpr int RPB = NWV / W;   // rows per workgroup
+  __shared__ float red[2][NWV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = wave % W;
   int64_t t = (int64_t)blockIdx.x * RPB + wave / W;
   const bool live = t < num_tokens;   // spare waves redo the last row and store nothing
@@ -292,14 +294,14 @@ using namespace va;
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-template <typename T, int MODE, int W, int CH>
+template <typename T, int MODE, int W, int CH, int NWV = 4>
 static void launch_row_vec(void* out, const void* in, int64_t in_stride, void* residual,
                            const void* weight, const float* scale, float* scales,
                            const float* scale_ub, float eps, int64_t num_tokens, int hidden,
                            hipStream_t st) {
-  constexpr int RPB = 4 / W;
-  hipLaunchKernelGGL((row_quant_vec_kernel<T, MODE, W, CH>),
-                     dim3((unsigned)((num_tokens + RPB - 1) / RPB)), dim3(ROW_THREADS), 0, st,
+  constexpr int RPB = NWV / W;
+  hipLaunchKernelGGL((row_quant_vec_kernel<T, MODE, W, CH, NWV>),
+                     dim3((unsigned)((num_tokens + RPB - 1) / RPB)), dim3(64 * NWV), 0, st,
                      (uint8_t*)out, (const T*)in, in_stride, (T*)residual, (const T*)weight, scale,
                      scales, scale_ub, eps, hidden, num_tokens);
 }
@@ -316,6 +318,8 @@ static bool launch_row_regs(void* out, const void* in, int64_t in_stride, void* 
   if (!vec) return false;
 #define LR(W, CH) launch_row_vec<T, MODE, W, CH>(out, in, in_stride, residual, weight, scale, scales, \
                                                  scale_ub, eps, num_tokens, hidden, st)
+#define LR8(W, CH) launch_row_vec<T, MODE, W, CH, 8>(out, in, in_stride, residual, weight, scale, scales, \
+                                                     scale_ub, eps, num_tokens, hidden, st)
   // at most 4 chunks per lane up to 8192 (8 chunks cost 230 VGPRs in the dynamic mode)
   // as few chunks per lane as the row allows (registers -> occupancy: 4096-wide rows measured
   // 1 wave x 8 chunks 19.4 us, 2 x 4 16.5, 4 x 2 15.9 for the dynamic mode, M = 4096)
@@ -323,9 +327,14 @@ static bool launch_row_regs(void* out, const void* in, int64_t in_stride, void* 
   else if (hidden <= 1024) LR(2, 1);
   else if (hidden <= 2048) LR(4, 1);
   else if (hidden <= 4096) LR(4, 2);
-  else if (hidden <= 8192) LR(4, 4);
-  else LR(4, 8);
+  // wider rows: 8 waves per row for the norm modes (two chunks per lane at 8192, like the 4096-wide
+  // rows: 4096 x 8192 dynamic 37.6 -> 27.0 us, + residual 52.9 -> 39.2, static + add 41.2 -> 35.8;
+  // 14336: 98.6 -> 45.5, 176 -> 80.4, 78.8 -> 65.7 us); plain per-token quantisation keeps 4 waves
+  // (17.7 vs 19.4 us at 8192, 29.1 vs 31.3 at 14336)
+  else if (hidden <= 8192) { if (MODE == MODE_QUANT) LR(4, 4); else LR8(8, 2); }
+  else { if (MODE == MODE_QUANT) LR(4, 8); else LR8(8, 4); }
 #undef LR
+#undef LR8
   return true;
 }
 
