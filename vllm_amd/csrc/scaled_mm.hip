@@ -341,7 +341,10 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
         if (i < 4 && t.bm > 64 && M <= t.bm / 2) continue;
         const int nt = ceil_div(M, t.bm) * ceil_div(N, t.bn);
         if (nt >= 190 || i == 4) {
-          sel = (nt >= 384 || K % (128 * t.kb) != 0) ? t.id : t.id_kb;
+          // (the 64 x 64 tile with 4 K blocks per barrier loses on long K loops: 14336 x 4096 at
+          // M 192 / 256 31.1 vs 25.3 / 27.5 us, 8192 x 4096 18.2 / 19.0 vs 16.0 / 16.6 us; at K 4096
+          // it wins, 8.5 vs 9.1 us -- profiles/r02_gemm_sweep_mid.csv)
+          sel = (nt >= 384 || K % (128 * t.kb) != 0 || (i == 3 && K >= 8192)) ? t.id : t.id_kb;
           // Even the smallest tile leaves half the CUs idle and the K loop is long: two K
           // slices (in-kernel fix-up, scaled_mm_large.hip).  The fix-up is a chain of three
           // device-scope round trips (~2.5 us), so it pays only here: 14336x4096, M 16..64:
