@@ -329,7 +329,7 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
     int splits = want_splits > 0 ? want_splits : 1;
     if (sel == 0 || sel == 11 || sel > 16) {
       // Largest tile that still yields ~3/4 of a full wave of workgroups (256 CUs); rows of
-      // a tile beyond M are wasted MFMA work, so BM <= 2 M.  With >= 1.5 waves of tiles the
+      // a tile beyond M are wasted MFMA work, so BM <= 2 M.  With more than one wave of tiles the
       // variant that fits several workgroups per CU wins, below that the variant that takes
       // KB K-blocks per barrier (measured: tools/sweep_gemm.py, profiles/r01_gemm_sweep.csv).
       struct GldsTile { int id, id_kb, bm, bn, kb; };
@@ -344,7 +344,10 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
           // (the 64 x 64 tile with 4 K blocks per barrier loses on long K loops: 14336 x 4096 at
           // M 192 / 256 31.1 vs 25.3 / 27.5 us, 8192 x 4096 18.2 / 19.0 vs 16.0 / 16.6 us; at K 4096
           // it wins, 8.5 vs 9.1 us -- profiles/r02_gemm_sweep_mid.csv)
-          sel = (nt >= 384 || K % (128 * t.kb) != 0 || (i == 3 && K >= 8192)) ? t.id : t.id_kb;
+          // (more than one round of tiles: the variant that fits two workgroups per CU -- 4096 x 6144
+          // at M 768 = 288 tiles of 128 x 128: 38.6 -> 30.2 us, at M 384 = 288 tiles of 128 x 64: 24.4 ->
+          // 20.6 us)
+          sel = (nt > 256 || K % (128 * t.kb) != 0 || (i == 3 && K >= 8192)) ? t.id : t.id_kb;
           // Even the smallest tile leaves half the CUs idle and the K loop is long: two K
           // slices (in-kernel fix-up, scaled_mm_large.hip).  The fix-up is a chain of three
           // device-scope round trips (~2.5 us), so it pays only here: 14336x4096, M 16..64:
