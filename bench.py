@@ -111,6 +111,7 @@ def time_gpu(fn, steps, warmup, dist=None):
 
 
 PRECONDITION_MS = 100.0
+GRAPH_WARM_MS = 25.0
 
 
 def precondition(fn, ms=PRECONDITION_MS):
@@ -149,8 +150,19 @@ def time_gpu_graph(fn, iters, replays=5):
             fn()
     g.replay()
     torch.cuda.synchronize()
+    # steady state: replay for ~GRAPH_WARM_MS first (the large GEMM runs 66-83 us for its first few
+    # hundred launches and 59 us after ~25 ms of continuous work: tools/gemm_drift.py)
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
+    warmed = 0.0
+    for _ in range(200):
+        if warmed >= GRAPH_WARM_MS:
+            break
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        warmed += max(e0.elapsed_time(e1), 0.05)
     e0.record()
     for _ in range(replays):
         g.replay()
