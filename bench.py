@@ -9,6 +9,10 @@ BASELINE.json configs[1]: Llama-3-8B shape, fp8 e4m3 KV with per-tensor scales,
 batch 64, ctx 4096, 32 q / 8 kv heads, head 128, block 16, bf16 query/output.
 Inputs are resident in HBM before the timed region.  `value` = algorithmic bytes
 (K and V once + q/out + block tables + seq_lens) / time.
+Steady state: a fresh process runs its first ~180 decode launches (~15 ms) 3-4 % slower than every
+launch after them (tools/decode_drift.py, profiles/r02_decode_drift.txt), so ~100 ms of untimed
+launches precede the W warmup steps (`roofline.steady_state`); the graph-timed legs of `extra`
+replay ~25 ms before their timed replays for the same reason.
 
 N > 1: one rank per GPU, either launched by torch.distributed.run (RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* in the env) or, when WORLD_SIZE is not set, by this script itself:
