@@ -21,6 +21,10 @@ for (M, H) in ((4096, 4096), (4096, 8192), (4096, 14336), (8192, 4096), (1024, 4
         "rms_dyn_res": (lambda: torch.ops._C.rms_norm_dynamic_per_token_quant(out, x, w, sc, 1e-6, None, res), M * H * 7),
         "add_rms_static": (lambda: torch.ops._C.fused_add_rms_norm_static_fp8_quant(out, x, res, w, one, 1e-6), M * H * 7),
     }
+    if H == 4096 and M >= 4096:
+        x2 = torch.randn((M, 2 * 14336), device=dev, dtype=torch.bfloat16)
+        o2 = torch.empty((M, 14336), device=dev, dtype=torch.float8_e4m3fn)
+        cases["silu_mul_quant_d14336"] = (lambda: torch.ops._C.silu_and_mul_quant(o2, x2, one), M * 14336 * 5)
     for name, (fn, nbytes) in cases.items():
         t = bench.time_gpu_graph(fn, 20)
         print(f"M={M} H={H} {name:16s} {t * 1e6:6.2f} us ({nbytes / t / 1e12:4.2f} TB/s)", flush=True)
