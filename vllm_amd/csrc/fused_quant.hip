@@ -15,6 +15,16 @@ constexpr float kQMax = 448.0f;
 constexpr int ROW_THREADS = 256;
 
 template <typename T> struct alignas(sizeof(T) * 8) Vec8 { T v[8]; };
+// 16 bytes with a non-temporal load (16-bit T)
+template <typename T>
+__device__ __forceinline__ Vec8<T> ld_stream(const Vec8<T>* p) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  static_assert(sizeof(Vec8<T>) == 16, "");
+  const u4 raw = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
+  Vec8<T> r;
+  __builtin_memcpy(&r, &raw, 16);
+  return r;
+}
 
 // block-wide reductions over ROW_THREADS threads; result valid in every thread
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -249,7 +259,7 @@ __device__ __forceinline__ float silu_mul(T x, T y) {
 template <typename T, bool VEC>
 __global__ __launch_bounds__(ROW_THREADS) void silu_mul_quant_kernel(
     uint8_t* __restrict__ out, const T* __restrict__ in, const float* __restrict__ scale_p,
-    int64_t num_tokens, int d, int tpb_log2) {
+    int64_t num_tokens, int d, int tpb_log2, int stream_loads) {
   const float inv = 1.0f / *scale_p;
   if constexpr (VEC) {
     const int cpt = d >> 3;   // chunks per token
@@ -257,8 +267,13 @@ __global__ __launch_bounds__(ROW_THREADS) void silu_mul_quant_kernel(
     const int64_t t = ((int64_t)blockIdx.x << tpb_log2) + (threadIdx.x >> pitch_log2);
     const int c = blockIdx.y * ROW_THREADS + (threadIdx.x & ((1 << pitch_log2) - 1));
     if (t >= num_tokens || c >= cpt) return;
-    const Vec8<T> x = reinterpret_cast<const Vec8<T>*>(in + t * 2 * d)[c];
-    const Vec8<T> y = reinterpret_cast<const Vec8<T>*>(in + t * 2 * d + d)[c];
+    // an input beyond the 256 MB Infinity Cache is streamed with non-temporal loads (8192 x 14336:
+    // 116.9 -> 100.2 us); a smaller one is most likely still cached from the kernel that wrote it,
+    // and plain loads are faster then (4096 x 14336: 42.4 vs 50.6 us; profiles/r02_row_quant_persistent.txt)
+    const Vec8<T>* px = reinterpret_cast<const Vec8<T>*>(in + t * 2 * d) + c;
+    const Vec8<T>* py = reinterpret_cast<const Vec8<T>*>(in + t * 2 * d + d) + c;
+    const Vec8<T> x = stream_loads ? ld_stream(px) : *px;
+    const Vec8<T> y = stream_loads ? ld_stream(py) : *py;
     float q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) q[j] = clamp_q(silu_mul<T>(x.v[j], y.v[j]) * inv);
@@ -453,9 +468,10 @@ extern "C" int vllm_amd_silu_and_mul_quant(void* out, const void* input, const f
     grid = dim3((unsigned)blocks);
   }
   hipStream_t st = (hipStream_t)stream;
+  const int stream_loads = num_tokens * 2 * (int64_t)d * 2 > (256ll << 20) ? 1 : 0;
 #define SM(T, V)                                                                          \
   hipLaunchKernelGGL((silu_mul_quant_kernel<T, V>), grid, dim3(ROW_THREADS),               \
-                     0, st, (uint8_t*)out, (const T*)input, scale, num_tokens, d, tpb_log2)
+                     0, st, (uint8_t*)out, (const T*)input, scale, num_tokens, d, tpb_log2, stream_loads)
   if (dtype == VLLM_AMD_F16) { if (vec) SM(f16_t, true); else SM(f16_t, false); }
   else { if (vec) SM(bf16_t, true); else SM(bf16_t, false); }
 #undef SM
