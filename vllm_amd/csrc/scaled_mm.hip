@@ -272,6 +272,10 @@ int launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
                            int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int asn, int bsn,
                            int out_dtype, bool vec, int splits, int ws_mode, hipStream_t st);
 bool scaled_mm_large_fits(int M, int N, int K, int64_t lda, int64_t ldb);
+// scaled_mm_pp.hip
+int launch_scaled_mm_pp(int variant, void* out, const void* a, const void* b, const float* a_scales,
+                        const float* b_scales, const void* bias, int M, int N, int K, int64_t lda,
+                        int64_t ldb, int64_t ldc, int asn, int bsn, int out_dtype, hipStream_t st);
 int g_mm_kernel = 0;   // tuning: 0 auto, 1 = register-staged 128x128, 2..10, 12, 13 = glds tile shapes
 int g_mm_splitk = 0;   // tuning: 0 auto, n >= 1 = n K slices (1 = never split)
 int g_mm_tail = 0;     // tuning: 0 auto, 1 = never give the last partial round of 256 x 256 tiles to 128 x 128 tiles
@@ -327,7 +331,19 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
     int sel = g_mm_kernel;
     const int want_splits = req_splits > 0 ? req_splits : g_mm_splitk;   // 0 = heuristic
     int splits = want_splits > 0 ? want_splits : 1;
-    if (sel == 0 || sel == 11 || sel > 16) {
+    if (sel >= 18 && sel <= 25) {
+      // the staggered / persistent 256 x 256 kernel (scaled_mm_pp.hip), forced: 18 plain, 19 stagger,
+      // 20 persistent, 21 both
+      const bool vec16 = ldc % 8 == 0 && N % 8 == 0 && ((((uintptr_t)out) & 15) == 0);
+      if (vec16) {
+        launch_scaled_mm_pp(sel - 18, out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc,
+                            a_scale_numel, b_scale_numel, out_dtype, st);
+        VA_LAUNCH_CHECK(op);
+        return VLLM_AMD_OK;
+      }
+      sel = 2;
+    }
+    if (sel == 0 || sel == 11 || sel > 17) {
       // Largest tile that still yields ~3/4 of a full wave of workgroups (256 CUs); rows of
       // a tile beyond M are wasted MFMA work, so BM <= 2 M.  With more than one wave of tiles the
       // variant that fits several workgroups per CU wins, below that the variant that takes

@@ -816,6 +816,7 @@ static int launch_glds_shape(int shape, const GldsArgs& g) {
     case 14: return launch_glds_t<out_t, 256, 256, 2, 2, 2, 1, false>(g);   // 4 waves, 128 x 128 each
     case 15: return launch_glds_t<out_t, 256, 256, 2, 4, 5, 1, false>(g);   // ring of five half stages
     case 16: return launch_glds_t<out_t, 256, 256, 2, 4, 2, 1, false, 1>(g);   // waves 4-7 stage everything
+    case 17: return launch_glds_t<out_t, 256, 256, 4, 4, 2, 1, false>(g);      // 16 waves, 64 x 64 each
     default: return launch_glds_t<out_t, 32, 128, 1, 4, 3, 2, true>(g);   // 13
   }
 }
@@ -834,8 +835,8 @@ int launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
                            int out_dtype, bool vec, int splits, int ws_mode, hipStream_t st) {
   // shape = a GldsTile::id of the table in scaled_mm.hip.  Shapes that consume KB blocks per
   // barrier need K % (128 KB) == 0; otherwise the same tile with KB = 1.
-  static const int kb_of[17] = {1, 1, 1, 1, 2, 1, 2, 1, 4, 1, 4, 1, 1, 2, 1, 1, 1};
-  if (shape < 2 || shape > 16 || shape == 11) shape = 3;
+  static const int kb_of[18] = {1, 1, 1, 1, 2, 1, 2, 1, 4, 1, 4, 1, 1, 2, 1, 1, 1, 1};
+  if (shape < 2 || shape > 17 || shape == 11) shape = 3;
   if (K % (LBK * kb_of[shape]) != 0) shape -= 1;
   const GldsArgs g{out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc, asn, bsn, vec, st,
                    splits, ws_mode};
