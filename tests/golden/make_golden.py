@@ -18,6 +18,8 @@ Sources of the expected outputs
                     (tests/kernels/quant_utils.py:22-97: ref_dynamic_per_token_quant,
                     ref_dynamic_per_tensor_fp8_quant) using torch.float8_e4m3fn casts
   scaled_mm_*.pt    torch CPU restatement of baseline_scaled_mm (tests/kernels/utils.py:1212-1251)
+  scaled_mm_torch_pertensor.pt  outputs of CPU torch._scaled_mm (scalar scales): the reference of the
+                    reference's own wvSplitKQ test (test_rocm_skinny_gemms.py:65-82)
   fp8_codec.pt      all 256 e4m3fn codes decoded by torch + an encode sweep by torch casts
   fused_quant_*.pt  torch CPU restatement of the "native" side of the reference's tests:
                     RMSNorm.forward_native (vllm/model_executor/layers/layernorm.py) followed by
@@ -172,6 +174,25 @@ def scaled_mm():
                                    out_bias=(ref + bias.float()).to(torch.bfloat16)))
 
 
+def scaled_mm_torch():
+    """Per-tensor scales: outputs of CPU torch._scaled_mm itself -- the reference its own skinny-GEMM test
+    compares wvSplitKQ with (tests/kernels/quantization/test_rocm_skinny_gemms.py:65-82, rtol 1e-2).  Cases
+    0-3: the wvSplitKQ call shapes (n <= 4 activation rows); 4-5: per-tensor cutlass_scaled_mm shapes."""
+    g = torch.Generator().manual_seed(21)
+    d = {}
+    cases = [(1, 256, 1024, torch.bfloat16), (2, 1000, 512, torch.bfloat16), (3, 256, 1024, torch.float16),
+             (4, 2048, 256, torch.bfloat16), (33, 208, 496, torch.bfloat16), (128, 256, 640, torch.float16)]
+    for i, (M, N, K, dt) in enumerate(cases):
+        a = (torch.rand((M, K), generator=g) - 0.5).to(torch.float8_e4m3fn)
+        w = (torch.rand((N, K), generator=g) - 0.5).to(torch.float8_e4m3fn)
+        sa, sb = torch.rand(1, generator=g) + 0.5, torch.rand(1, generator=g) + 0.5
+        out = torch._scaled_mm(a, w.t(), scale_a=sa.reshape(()), scale_b=sb.reshape(()), out_dtype=dt)
+        d.update({f"a{i}": a.view(torch.uint8), f"w{i}": w.view(torch.uint8), f"sa{i}": sa, f"sb{i}": sb,
+                  f"out{i}": out})
+    d["n"] = torch.tensor(len(cases))
+    save("scaled_mm_torch_pertensor.pt", d)
+
+
 def fp8_codec():
     codes = torch.arange(256, dtype=torch.uint8)
     dec = codes.view(torch.float8_e4m3fn).float()
@@ -263,4 +284,4 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        attention(); attention_fp8kv(); cache(); fp8_quant(); scaled_mm(); fp8_codec(); fused_quant(); slot_mapping()
+        attention(); attention_fp8kv(); cache(); fp8_quant(); scaled_mm(); scaled_mm_torch(); fp8_codec(); fused_quant(); slot_mapping()

@@ -248,6 +248,42 @@ def test_fp8kv_reference_executed_golden(ops, path, version, v1_form):
     assert (out.cpu().float() - want.float()).abs().max().item() < 2e-3
 
 
+@pytest.mark.parametrize("path", sorted(_glob.glob(_os.path.join(_GOLD, "attn_ref_*.pt"))),
+                         ids=lambda p: _os.path.basename(p))
+@pytest.mark.parametrize("version", ["v1", "v2", "rocm"])
+def test_16_32bit_kv_reference_executed_golden(ops, path, version):
+    """HIP decode over bf16 / fp16 / fp32 KV straight against the outputs of the reference's own CPU kernels
+    (csrc/cpu/attention.cpp compiled as oracle/_ref, tests/golden/make_golden.py attention) -- no oracle in
+    between -- at the reference's tolerance (test_attention.py:345-348): atol 1e-3, rtol 1e-5."""
+    d = torch.load(path, weights_only=True)
+    q, kc, vc, bt, sl = (d[k].cuda() for k in ("q", "kc", "vc", "bt", "sl"))
+    if version == "rocm" and q.dtype == torch.float32:
+        pytest.skip("the rocm op takes 16-bit queries only (platforms/rocm.py:138-148)")
+    KVH, scale = int(d["num_kv_heads"]), float(d["scale"])
+    slopes = d["slopes"].cuda() if "slopes" in d else None
+    one = torch.ones(1, device="cuda")
+    max_len = int(d["sl"].max())
+    S, H, D = q.shape
+    out = torch.full_like(q, float("nan"))
+    if version == "v1":
+        ops.paged_attention_v1(out, q, kc, vc, KVH, scale, bt, sl, 16, max_len, slopes, "auto", one, one)
+        want = d["out_v1"]
+    else:
+        PS = 512 if version == "v2" else 256
+        P = (max_len + PS - 1) // PS
+        es = torch.zeros((S, H, P), device="cuda"); ml = torch.zeros_like(es)
+        tmp = torch.zeros((S, H, P, D), dtype=q.dtype, device="cuda")
+        if version == "v2":
+            ops.paged_attention_v2(out, es, ml, tmp, q, kc, vc, KVH, scale, bt, sl, 16, max_len,
+                                   slopes, "auto", one, one)
+        else:
+            ops.paged_attention_rocm(out, es, ml, tmp, q, kc, vc, KVH, scale, bt, sl, None, 16,
+                                     max_len, slopes, "auto", one, one)
+        want = d["out_v2"]
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu().float(), want.float(), atol=1e-3, rtol=1e-5)
+
+
 @pytest.mark.parametrize("kv", ["auto", "fp8"])
 @pytest.mark.parametrize("lens", [
     [4096, 1, 64, 65, 700, 3000, 17],             # one long sequence shared by many workgroups

@@ -218,6 +218,27 @@ def test_fp8_nan_inf_encoding(ops, oracle):
     assert torch.equal(got & 0x7f, out_o & 0x7f)
 
 
+@pytest.mark.parametrize("tag", ["bf16", "fp16", "fp32"])
+def test_reshape_and_cache_reference_executed_golden(ops, tag):
+    """HIP reshape_and_cache / reshape_and_cache_flash straight against the caches the reference's own CPU
+    kernel wrote (csrc/cpu/cache.cpp compiled as oracle/_ref; tests/golden/cache_ref_*.pt): exact
+    (test_cache.py:212-213)."""
+    import os
+    d = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"cache_ref_{tag}.pt"),
+                   weights_only=True)
+    key, value, slots = d["key"].cuda(), d["value"].cuda(), d["slots"].cuda()
+    kc, vc = torch.zeros_like(d["kc"]).cuda(), torch.zeros_like(d["vc"]).cuda()
+    one = torch.ones(1, device="cuda")
+    ops.reshape_and_cache(key, value, kc, vc, slots, "auto", one, one)
+    assert torch.equal(kc.cpu(), d["kc"]) and torch.equal(vc.cpu(), d["vc"])
+    NB, H, _, BS, _ = d["kc"].shape
+    D = d["vc"].shape[2]
+    kf = torch.zeros((NB, BS, H, D), dtype=kc.dtype, device="cuda"); vf = torch.zeros_like(kf)
+    ops.reshape_and_cache_flash(key, value, kf, vf, slots, "auto", one, one)
+    assert torch.equal(vf.permute(0, 2, 3, 1).cpu(), d["vc"])
+    assert torch.equal(kf.permute(0, 2, 3, 1).cpu(), d["kc"].permute(0, 1, 2, 4, 3).reshape(NB, H, D, BS))
+
+
 def test_copy_blocks(ops):
     NB, L = 32, 3
     g = torch.Generator().manual_seed(2)

@@ -99,6 +99,68 @@ def test_wvSplitKQ(ops, oracle, n, mk):
     torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=1e-2, atol=1e-3)
 
 
+def test_torch_scaled_mm_pertensor_golden(ops):
+    """HIP wvSplitKQ and per-tensor cutlass_scaled_mm straight against outputs of CPU torch._scaled_mm
+    (tests/golden/scaled_mm_torch_pertensor.pt): the reference's own comparison for wvSplitKQ
+    (test_rocm_skinny_gemms.py:65-82), at its rtol 1e-2."""
+    import os
+    d = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                "scaled_mm_torch_pertensor.pt"), weights_only=True)
+    for i in range(int(d["n"])):
+        a = d[f"a{i}"].view(torch.float8_e4m3fn).cuda()      # activations [n, K]
+        w = d[f"w{i}"].view(torch.float8_e4m3fn).cuda()      # weights [m, K]
+        sa, sb, want = d[f"sa{i}"].cuda(), d[f"sb{i}"].cuda(), d[f"out{i}"]
+        out = ops.cutlass_scaled_mm(a, w.t(), sa.reshape(1, 1), sb.reshape(1, 1), want.dtype)
+        torch.testing.assert_close(out.cpu().float(), want.float(), rtol=1e-2, atol=1e-3)
+        if a.shape[0] <= 4:
+            out = ops.wvSplitKQ(w, a, want.dtype, sb, sa, 256)
+            torch.testing.assert_close(out.cpu().float(), want.float(), rtol=1e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("KN", [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)])
+@pytest.mark.parametrize("M", [1024, 4096])
+def test_scaled_mm_configs2_large_m_sampled_oracle(ops, oracle, KN, M):
+    """configs[2] at large M on RANDOM data (per-token x per-channel scales, random mantissas over the full
+    K): the oracle on a sample of 64 rows x 64 columns of the output, same tolerance as the small shapes.
+    Twice: repeated launches of the persistent kernel agree to the bit."""
+    K, N = KN
+    g = torch.Generator(device="cuda").manual_seed(K + N + M)
+    a = torch.randn((M, K), generator=g, device="cuda").to(torch.float8_e4m3fn)
+    w = torch.randn((N, K), generator=g, device="cuda").to(torch.float8_e4m3fn)
+    sa = (torch.rand((M, 1), generator=g, device="cuda") + 0.5) * 0.02
+    sb = (torch.rand((N, 1), generator=g, device="cuda") + 0.5) * 0.02
+    out = ops.cutlass_scaled_mm(a, w.t(), sa, sb, torch.bfloat16)
+    again = ops.cutlass_scaled_mm(a, w.t(), sa, sb, torch.bfloat16)
+    assert torch.equal(out, again)
+    cg = torch.Generator().manual_seed(M + N)
+    rows = torch.cat([torch.tensor([0, 255, 256, M - 1]), torch.randint(0, M, (60,), generator=cg)])
+    cols = torch.cat([torch.tensor([0, 255, 256, N - 1]), torch.randint(0, N, (60,), generator=cg)])
+    ref = oracle.scaled_mm(a[rows.cuda()].cpu().view(torch.uint8), w[cols.cuda()].cpu().view(torch.uint8).t(),
+                           sa[rows.cuda()].cpu(), sb[cols.cuda()].cpu(), torch.bfloat16)
+    got = out[rows.cuda()][:, cols.cuda()].cpu()
+    torch.testing.assert_close(got.float(), ref.float(), rtol=1.6e-2, atol=5e-3)
+
+
+@pytest.mark.parametrize("MNK", [(4096, 4096, 1024), (1000, 1288, 1024), (2304, 2816, 512), (4096, 10240, 384)])
+def test_scaled_mm_pp_variants_identical(ops, MNK):
+    """The staggered / persistent forms of the 256 x 256 kernel (scaled_mm_pp.hip, "mm_kernel" 18-25) keep
+    the K order and the MFMA of the kernel of scaled_mm_large.hip ("mm_kernel" 2): bit-identical outputs on
+    random operands, with bias, ragged edges, one and several tiles per workgroup."""
+    from vllm_amd import _lib
+    M, N, K = MNK
+    a, w, sa, sb, b = make(M, N, K, M + N, True, True, torch.bfloat16, True)
+    a, w, sa, sb, b = a.cuda(), w.cuda(), sa.cuda(), sb.cuda(), b.cuda()
+    try:
+        outs = {}
+        for k in (2, 18, 19, 20, 21, 23, 25, 0):
+            _lib.set_tuning("mm_kernel", k)
+            outs[k] = ops.cutlass_scaled_mm(a, w.t(), sa, sb, torch.bfloat16, b)
+    finally:
+        _lib.set_tuning("mm_kernel", 0)
+    for k, o in outs.items():
+        assert torch.equal(o, outs[2]), k
+
+
 @pytest.fixture
 def force_kernel():
     """Pin the GEMM kernel choice (vllm_amd_set_tuning "mm_kernel"); back to auto afterwards."""
@@ -112,7 +174,7 @@ def force_kernel():
     _lib.set_tuning("mm_splitk", 0)
 
 
-@pytest.mark.parametrize("kernel", list(range(1, 17)))
+@pytest.mark.parametrize("kernel", list(range(1, 26)))
 @pytest.mark.parametrize("MNK", [(300, 520, 256), (256, 256, 1024), (257, 971, 384), (640, 1288, 2048),
                                  (40, 8, 128 * 3), (5, 264, 512), (32, 1040, 1024)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
@@ -125,7 +187,7 @@ def test_scaled_mm_every_tile_kernel(ops, oracle, force_kernel, kernel, MNK, out
     check(ops, oracle, M, N, K, False, False, out_dtype, bias=False, seed=M + N + kernel)
 
 
-@pytest.mark.parametrize("kernel", list(range(1, 11)) + [12, 13, 14, 15, 16])
+@pytest.mark.parametrize("kernel", list(range(1, 11)) + list(range(12, 26)))
 def test_scaled_mm_integer_exact_every_kernel(ops, force_kernel, kernel):
     M, N, K = 512, 768, 640
     g = torch.Generator().manual_seed(kernel)
@@ -156,11 +218,11 @@ def test_scaled_mm_large_auto(ops):
 
 @pytest.mark.parametrize("MN", [(4096, 6144), (4000, 6144), (3584, 6144), (3500, 6144), (2048, 10240), (4096, 4096)])
 @pytest.mark.parametrize("per_channel", [True, False])
-def test_scaled_mm_tail_round_split(ops, MN, per_channel):
-    """Shapes whose 256 x 256 tiles end in a round that covers at most half the CUs run as two
-    launches (the tail columns with 128 x 128 tiles, scaled_mm.hip): small-integer operands and
-    power-of-two scales make every sum exact, so the result equals the fp32 matmul bit for bit,
-    in both column ranges, with per-channel scales and bias addressed past the seam."""
+def test_scaled_mm_several_tiles_per_workgroup(ops, MN, per_channel):
+    """Shapes with more 256 x 256 tiles than CUs: a workgroup of the persistent kernel (scaled_mm_pp.hip)
+    walks several tiles, unevenly (384 tiles = 1.5 per workgroup), with ragged M: small-integer operands
+    and power-of-two scales make every sum exact, so the result equals the fp32 matmul bit for bit, with
+    per-channel scales and bias addressed per tile."""
     M, N = MN
     K = 384
     g = torch.Generator().manual_seed(M + N)

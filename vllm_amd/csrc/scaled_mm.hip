@@ -278,7 +278,7 @@ int launch_scaled_mm_pp(int variant, void* out, const void* a, const void* b, co
                         int64_t ldb, int64_t ldc, int asn, int bsn, int out_dtype, hipStream_t st);
 int g_mm_kernel = 0;   // tuning: 0 auto, 1 = register-staged 128x128, 2..10, 12, 13 = glds tile shapes
 int g_mm_splitk = 0;   // tuning: 0 auto, n >= 1 = n K slices (1 = never split)
-int g_mm_tail = 0;     // tuning: 0 auto, 1 = never give the last partial round of 256 x 256 tiles to 128 x 128 tiles
+int g_mm_tail = 0;     // tuning key kept for old scripts; the tail split went away with the persistent kernel
 }  // namespace va
 
 using namespace va;
@@ -377,27 +377,16 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
     if (sel >= 2) {
       // 16-byte row-contiguous stores through LDS
       const bool vec16 = ldc % 8 == 0 && N % 8 == 0 && ((((uintptr_t)out) & 15) == 0);
-      // Tile quantisation of the 256 x 256 kernel: when the last round covers at most half of
-      // the 256 CUs (4096 x 6144: 384 tiles = 1.5 rounds cost 2), the whole columns of tiles in
-      // that round go to a second launch with 128 x 128 tiles, which fills the chip again.
-      if (sel == 2 && g_mm_kernel == 0 && g_mm_tail == 0 && splits == 1 && vec16 && N % 256 == 0) {
-        const int tm = ceil_div(M, 256), tn = N / 256, rem = (tm * tn) % 256;
-        const int c = ceil_div(rem, tm);            // columns of tiles that leave the first launch
-        const int first = tm * (tn - c);            // its tiles: whole rounds, or nearly so
-        if (tm * tn > 256 && rem > 0 && rem <= 128 && first > 0 &&
-            (first % 256 == 0 || first % 256 >= 240) && ceil_div(M, 128) * c * 2 >= 320) {
-          const int n2 = c * 256, n1 = N - n2;
-          const int64_t osz = 2;   // bf16 / f16
-          launch_scaled_mm_large(2, out, a, b, a_scales, b_scales, bias, M, n1, K, lda, ldb, ldc,
-                                 a_scale_numel, b_scale_numel == 1 ? 1 : n1, out_dtype, vec16, 1, 0, st);
-          launch_scaled_mm_large(3, (char*)out + n1 * osz, a, (const char*)b + (int64_t)n1 * ldb,
-                                 a_scales, b_scale_numel == 1 ? b_scales : b_scales + n1,
-                                 bias ? (const char*)bias + n1 * osz : nullptr, M, n2, K, lda, ldb,
-                                 ldc, a_scale_numel, b_scale_numel == 1 ? 1 : n2, out_dtype, vec16, 1,
-                                 0, st);
-          VA_LAUNCH_CHECK(op);
-          return VLLM_AMD_OK;
-        }
+      // MFMA-bound problems (the heuristic's 256 x 256 choice): the staggered, persistent kernel of
+      // scaled_mm_pp.hip -- waves 4-7 half a K block behind waves 0-3, one workgroup per CU walking its
+      // XCD's share of the tiles (4096^3 55.9 -> 49.3 us, K 14336 170.7 -> 154.0, N 28672 405 -> 334,
+      // N 6144 100 (92.7 with the tail split below) -> 85.1: profiles/r03_gemm_pp.txt).  It writes 16-byte
+      // pieces of rows, so outputs that do not allow them keep the kernel of scaled_mm_large.hip.
+      if (sel == 2 && g_mm_kernel == 0 && splits == 1 && vec16) {
+        launch_scaled_mm_pp(3, out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc,
+                            a_scale_numel, b_scale_numel, out_dtype, st);
+        VA_LAUNCH_CHECK(op);
+        return VLLM_AMD_OK;
       }
       const int rc = launch_scaled_mm_large(sel, out, a, b, a_scales, b_scales, bias, M, N, K, lda,
                                             ldb, ldc, a_scale_numel, b_scale_numel, out_dtype, vec16,

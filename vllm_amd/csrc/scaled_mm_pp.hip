@@ -208,46 +208,55 @@ __global__ __launch_bounds__(64 * NW) void scaled_mm_pp_kernel(
     for (int mt = 0; mt < MT; ++mt) sav[mt] = a_scales[a_scale_numel == 1 ? 0 : min(m0 + mt * 16 + c16, M - 1)];
     uint8_t* mine = lds + EPI_OFF + wave * EPI_WAVE;
     const int rrow = lane >> 3, rch = lane & 7;   // read-back: row within 8, 16-byte chunk
+    // store address of (row rrow, chunk rch) of sub-tile 0; a row down = ldc8 16-byte units
+    const bool ncol_ok = n0 + 8 * rch < N && store_mode != 3;
+    u32x4* orow = reinterpret_cast<u32x4*>(out + (int64_t)(m0 + rrow) * ldc + n0 + 8 * rch);
+    const int64_t ldc8 = ldc / 8;   // host: ldc % 8 == 0
     // software pipeline over the m-steps: sub-tile mt is written to buffer mt & 1 while sub-tile mt - 1 is
-    // read back from the other buffer and stored
-    static_for<MT + 1>([&](auto ic) {
-      constexpr int mt = decltype(ic)::value;
-      u32x4 v[2];
-      if constexpr (mt > 0) {
-        const uint8_t* rb = mine + ((mt - 1) & 1) * 2048;
+    // read back from the other buffer and stored.  Two copies behind ONE wave-uniform branch: with the
+    // bias folded in by a select per element the loop is VALU-bound (9 instead of 3 instructions per output).
+    auto body = [&](auto with_bias) __attribute__((always_inline)) {
+      constexpr bool BIAS = decltype(with_bias)::value;
+      static_for<MT + 1>([&](auto ic) {
+        constexpr int mt = decltype(ic)::value;
+        u32x4 v[2];
+        if constexpr (mt > 0) {
+          const uint8_t* rb = mine + ((mt - 1) & 1) * 2048;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int row = 8 * i + rrow;
-          v[i] = *reinterpret_cast<const u32x4*>(rb + row * 128 + ((rch ^ (row & 7)) << 4));
-        }
-      }
-      if constexpr (mt < MT) {
-        uint8_t* wb = mine + (mt & 1) * 2048;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          struct alignas(8) V4 { out_t e[4]; } pk;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float x = acc[nt][mt][r] * sav[mt];
-            x = x * sbv[nt][r];
-            out_t o = from_f32<out_t>(x);
-            if (has_bias) o = from_f32<out_t>(to_f32(o) + to_f32(bv[nt][r]));
-            pk.e[r] = o;
+          for (int i = 0; i < 2; ++i) {
+            const int row = 8 * i + rrow;
+            v[i] = *reinterpret_cast<const u32x4*>(rb + row * 128 + ((rch ^ (row & 7)) << 4));
           }
-          const int ch = (2 * nt + (g4 >> 1)) ^ (c16 & 7);
-          *reinterpret_cast<V4*>(wb + c16 * 128 + (ch << 4) + (g4 & 1) * 8) = pk;
         }
-      }
-      if constexpr (mt > 0) {
+        if constexpr (mt < MT) {
+          uint8_t* wb = mine + (mt & 1) * 2048;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int m = m0 + (mt - 1) * 16 + 8 * i + rrow, n = n0 + 8 * rch;
-          if (m < M && n < N && store_mode != 3)
-            __builtin_nontemporal_store(v[i], reinterpret_cast<u32x4*>(out + (int64_t)m * ldc + n));
+          for (int nt = 0; nt < NT; ++nt) {
+            struct alignas(8) V4 { out_t e[4]; } pk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x = acc[nt][mt][r] * sav[mt];
+              x = x * sbv[nt][r];
+              out_t o = from_f32<out_t>(x);
+              if constexpr (BIAS) o = from_f32<out_t>(to_f32(o) + to_f32(bv[nt][r]));
+              pk.e[r] = o;
+            }
+            const int ch = (2 * nt + (g4 >> 1)) ^ (c16 & 7);
+            *reinterpret_cast<V4*>(wb + c16 * 128 + (ch << 4) + (g4 & 1) * 8) = pk;
+          }
         }
-      }
-      __builtin_amdgcn_wave_barrier();
-    });
+        if constexpr (mt > 0) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int m = m0 + (mt - 1) * 16 + 8 * i + rrow;
+            if (m < M && ncol_ok) __builtin_nontemporal_store(v[i], orow + (int64_t)(8 * i + (mt - 1) * 16) * ldc8);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      });
+    };
+    if (has_bias) body(std::true_type{});
+    else body(std::false_type{});
   };
 
   // ---- K loop over the blocks of all this workgroup's tiles ---------------------------------
