@@ -190,10 +190,14 @@ def run_attention(cfg, steps, warmup, device, dist=None, version="auto"):
         return PagedAttention.forward_decode(q, kc, vc, bt, sl, ctx, kvd, KVH, D ** -0.5, None,
                                              one, one)
 
+    # cold: exactly the driver's W warmups + K timed steps as the first launches of the process ...
+    cold_wall, cold_ev = time_gpu(step, steps, warmup, dist)
+    # ... and the steady state: the same W + K after ~100 ms of untimed launches
     pre = precondition(step)
     wall, ev = time_gpu(step, steps, warmup, dist)
     nbytes = attention_bytes(S, ctx, H, KVH, D, BS, 1 if fp8 else 2)
-    return dict(wall=wall, event=ev, bytes=nbytes, precondition_launches=pre)
+    return dict(wall=wall, event=ev, bytes=nbytes, precondition_launches=pre, cold_wall=cold_wall,
+                cold_event=cold_ev)
 
 
 def run_attention_shape(name, S, ctx, H, KVH, device, dist=None, world=1, iters=20, D=128, BS=16):
@@ -246,27 +250,70 @@ def run_ragged_decode(device, iters=20):
                 frac_of_hbm_peak=round(nbytes / per / 1e9 / HBM_PEAK_GBPS, 4))
 
 
-def run_scaled_mm(device, shapes, Ms, iters=20):
+MALL_BYTES = 256 << 20          # Infinity Cache (MI355X_MICROARCH.md)
+
+
+def run_scaled_mm(device, shapes, Ms, iters=20, rotate=True):
+    """configs[2] grid.  The weight operand ROTATES through enough copies that together they exceed the
+    256 MiB Infinity Cache (every (K, N) here is <= 117 MB: a single replayed copy would be served from
+    that cache and the small-M "GB/s" would not be HBM numbers), so each launch streams its
+    weights from HBM.  Activations, scales and the output are one buffer each (L2 / cache resident, as
+    they are behind the producing kernel in a model)."""
     from vllm_amd import _custom_ops as ops
     res = []
     for (K, N) in shapes:
-        w = torch.randn((N, K), device=device, dtype=torch.bfloat16)
-        wq, ws = ops.scaled_fp8_quant(w, use_per_token_if_dynamic=True)
-        del w
+        copies = max(3, -(-int(1.25 * MALL_BYTES) // (K * N))) if rotate else 1
+        copies = int(os.environ.get("VLLM_AMD_BENCH_WEIGHT_COPIES", copies))   # (experiments)
+        wqs = []
+        for c in range(copies):
+            w = torch.randn((N, K), device=device, dtype=torch.bfloat16)
+            wq, ws = ops.scaled_fp8_quant(w, use_per_token_if_dynamic=True)
+            wqs.append((wq.t(), ws))
+            del w
+        n_calls = -(-iters // copies) * copies      # whole turns of the rotation per graph
         for M in Ms:
             a = torch.randn((M, K), device=device, dtype=torch.bfloat16)
             aq, as_ = ops.scaled_fp8_quant(a, use_per_token_if_dynamic=True)
             out = torch.empty((M, N), dtype=torch.bfloat16, device=device)
-            wt = wq.t()
-            fn = lambda: torch.ops._C.cutlass_scaled_mm(out, aq, wt, as_, ws, None)
-            t = time_gpu_graph(fn, iters)
+            state = {"i": 0}
+
+            def fn():
+                wt, ws = wqs[state["i"] % copies]
+                state["i"] += 1
+                torch.ops._C.cutlass_scaled_mm(out, aq, wt, as_, ws, None)
+            state["i"] = 0
+            t = time_gpu_graph(fn, n_calls)
             flops = 2.0 * M * N * K
             nbytes = M * K + K * N + 2 * M * N + 4 * (M + N)
             bound = min(FP8_DENSE_PEAK_TFLOPS, HBM_PEAK_GBPS * 1e9 * (flops / nbytes) / 1e12)
             res.append(dict(M=M, K=K, N=N, us=round(t * 1e6, 2), tflops=round(flops / t / 1e12, 2),
                             gbps=round(nbytes / t / 1e9, 1), roof_tflops=round(bound, 1),
-                            frac=round(flops / t / 1e12 / bound, 4)))
+                            frac=round(flops / t / 1e12 / bound, 4), weight_copies=copies))
+        del wqs
+        torch.cuda.empty_cache()
     return res
+
+
+def run_mfma_ceiling(device):
+    """What the matrix pipes deliver with nothing else to do: a loop of the GEMM's own fp8 MFMA on random
+    operands held in registers, 8 waves per CU (vllm_amd_mfma_ceiling; tools/mfmabench2.hip).  The 5 PF paper
+    peak assumes 2.4 GHz; under load the chip holds 1.7-2.1 GHz."""
+    from vllm_amd import _lib
+    sink = torch.empty(256 * 512, dtype=torch.float32, device=device)
+    iters = 4000
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        _lib.check(_lib.lib.vllm_amd_mfma_ceiling(sink.data_ptr(), iters, st))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        _lib.check(_lib.lib.vllm_amd_mfma_ceiling(sink.data_ptr(), iters, st))
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / 5
+    flops = 256.0 * 8 * iters * 32 * 2 * 16 * 16 * 128
+    return round(flops / t / 1e12, 1)
 
 
 def run_cache_quant(device, iters=20):
@@ -615,11 +662,11 @@ def main():
     r = run_attention(cfg, args.steps, args.warmup, device, dist)
     wall = r["wall"]
     if use_dist:
-        t = torch.tensor([wall, r["event"]], dtype=torch.float64, device=device)
+        t = torch.tensor([wall, r["event"], r["cold_wall"], r["cold_event"]], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, ev = t.tolist()
+        wall, ev, cold_wall, cold_ev = t.tolist()
     else:
-        ev = r["event"]
+        ev, cold_wall, cold_ev = r["event"], r["cold_wall"], r["cold_event"]
     total_bytes = r["bytes"] * world * args.steps
     value = total_bytes / wall / 1e9
     per_launch = ev / args.steps
@@ -628,12 +675,25 @@ def main():
     # HBM bytes per launch: from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
     # profiles/), not re-measured in this run
     traffic, traffic_src = None, None
-    for name in ("r02_attention_pmc.json", "r01_attention_pmc.json"):
+    for name in ("r03_attention_pmc.json", "r02_attention_pmc.json", "r01_attention_pmc.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             traffic_src = "profiles/" + name + " (committed rocprofv3 --pmc passes, not this run)"
             break
+
+    # the same kernel's average duration in the COMMITTED rocprofv3 --kernel-trace --stats run (the tracer costs
+    # ~1.7 us per launch: profiles/r02_decode_drift.txt)
+    trace_us, trace_cold_us, trace_src = None, None, None
+    for name in ("r03_attention_pmc.json", "r02_attention_pmc.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc):
+            pj = json.load(open(pmc))
+            trace_us, trace_cold_us = pj.get("kernel_trace_avg_us"), pj.get("kernel_trace_cold_avg_us")
+            if trace_us:
+                trace_src = "profiles/" + name + " (committed rocprofv3 --kernel-trace run, not this run)"
+                break
+    cold_per = cold_ev / args.steps
 
     line = {
         "metric": "paged-attn decode HBM GB/s (% peak) + fp8 scaled_mm TFLOPS at 1/2/4/8 GPUs",
@@ -659,6 +719,17 @@ def main():
                      "traffic_source": traffic_src,
                      "kernel": "pa_mfma_kernel<bf16, fp8, 128, 16>",
                      "us_per_launch": round(per_launch * 1e6, 2),
+                     "frac_kernel_trace": (round(r["bytes"] / (trace_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+                                           if trace_us else None),
+                     "frac_kernel_trace_cold": (round(r["bytes"] / (trace_cold_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+                                                if trace_cold_us else None),
+                     "kernel_trace_avg_us": trace_us, "kernel_trace_cold_avg_us": trace_cold_us,
+                     "kernel_trace_source": trace_src,
+                     "cold": {"what": f"the process's first {args.warmup} + {args.steps} launches (no "
+                                      "preconditioning): W warmups, K timed",
+                              "us_per_launch": round(cold_per * 1e6, 2),
+                              "frac": round(r["bytes"] / cold_per / 1e9 / HBM_PEAK_GBPS, 4),
+                              "value_gbps": round(total_bytes / cold_wall / 1e9, 1)},
                      "algorithmic_bytes_per_launch": r["bytes"],
                      "steady_state": f"{r['precondition_launches']} untimed launches (~{PRECONDITION_MS:.0f} ms) before "
                                      f"the {args.warmup} warmup steps: the first ~200 launches of a process run "
@@ -673,6 +744,12 @@ def main():
             best = max(extra["scaled_mm"], key=lambda e: e["tflops"])
             extra["scaled_mm_best_tflops"] = best["tflops"]
             extra["scaled_mm_pct_of_fp8_peak"] = round(100 * best["tflops"] / FP8_DENSE_PEAK_TFLOPS, 2)
+            # the matrix pipes' own random-data rate under the chip's power management, measured in this run
+            ceil = run_mfma_ceiling(device)
+            extra["mfma_random_data_ceiling_tflops"] = ceil
+            extra["scaled_mm_best_frac_of_mfma_ceiling"] = round(best["tflops"] / ceil, 4)
+            extra["scaled_mm_note"] = ("weights rotate through `weight_copies` buffers (> 256 MiB in all): every "
+                                       "launch streams them from HBM; frac = TFLOP/s over min(5 PF, 8 TB/s x AI)")
             extra["cache_quant"] = run_cache_quant(device)
             extra["fused_neighbours"] = run_fused_neighbours(device)
             extra["prefill_attention"] = run_prefill(device)

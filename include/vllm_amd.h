@@ -241,6 +241,13 @@ int vllm_amd_scaled_mm_static(void* out, const void* a, const void* b,
                               int64_t ldb, int64_t ldc, int a_scale_numel,
                               int b_scale_numel, int out_dtype, int splits, void* stream);
 
+/* No counterpart in the reference: a measurement helper for bench.py.  Runs a loop of nothing but the fp8 MFMA
+ * the GEMM kernels use (v_mfma_scale_f32_16x16x128_f8f6f4, pseudo-random operands held in registers, 8 waves
+ * on each of 256 workgroups) so that the GEMM's TFLOP/s can be read against what the matrix pipes deliver
+ * under the chip's power management, not only against the 5 PF paper peak.  sink: 256 * 512 floats of device
+ * memory; FLOP per call = 256 * 8 * iters * 32 * 2 * 16 * 16 * 128. */
+int vllm_amd_mfma_ceiling(void* sink, int iters, void* stream);
+
 /* Replaces torch.ops._rocm_C.wvSplitKQ
  *   schema csrc/rocm/torch_bindings.cpp:34-37, csrc/rocm/skinny_gemms.cu:1649-1714,
  *   python vllm/_custom_ops.py:1501-1508.

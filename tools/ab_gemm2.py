@@ -12,7 +12,8 @@ ap.add_argument("--configs", default="2;21")
 ap.add_argument("--shapes", default="4096x4096x4096,4096x14336x4096,4096x4096x28672,4096x4096x6144")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--defaults", default="mm_patch=4")
+ap.add_argument("--defaults", default="mm_patch=8,mm_store=0,mm_prio=0")
+ap.add_argument("--no-rotate", action="store_true", help="one weight buffer (Infinity-Cache resident) instead of the rotation")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 defaults = dict(kv.split("=") for kv in a.defaults.split(",") if kv)
@@ -28,7 +29,7 @@ for sh in a.shapes.split(","):
             for key, v in {**defaults, **kv}.items():
                 _lib.set_tuning(key, int(v))
             _lib.set_tuning("mm_kernel", k)
-            r = bench.run_scaled_mm(dev, [(K, N)], [M], a.iters)[0]
+            r = bench.run_scaled_mm(dev, [(K, N)], [M], a.iters, rotate=not a.no_rotate)[0]
             ts[name].append(r["us"])
     _lib.set_tuning("mm_kernel", 0)
     print(f"M={M} K={K} N={N}: " + "  ".join(

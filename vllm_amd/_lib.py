@@ -47,6 +47,7 @@ SIGNATURES = {
     "vllm_amd_set_workspace": [_vp, _i64, _vp],
     "vllm_amd_scaled_mm_static": [
         _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _i, _i, _vp],
+    "vllm_amd_mfma_ceiling": [_vp, _i, _vp],
     "vllm_amd_wvSplitKQ": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "vllm_amd_rms_norm_static_fp8_quant": [_vp, _vp, _vp, _vp, _f, _i64, _i, _i64, _i, _vp],
     "vllm_amd_fused_add_rms_norm_static_fp8_quant": [

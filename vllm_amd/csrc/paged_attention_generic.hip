@@ -29,6 +29,7 @@ extern int g_mm_splitk;
 extern int g_mm_tail;
 extern int g_mm_patch;
 extern int g_mm_store;
+extern int g_mm_prio;
 extern int g_cache_runs;
 extern int g_pf_rows;   // prefill_attention.hip
 extern int g_uni_decode;
@@ -574,6 +575,7 @@ extern "C" int vllm_amd_set_tuning(const char* key, int value) {
   if (strcmp(key, "mm_tail") == 0) { g_mm_tail = value; return VLLM_AMD_OK; }
   if (strcmp(key, "mm_patch") == 0) { g_mm_patch = value; return VLLM_AMD_OK; }
   if (strcmp(key, "mm_store") == 0) { g_mm_store = value; return VLLM_AMD_OK; }
+  if (strcmp(key, "mm_prio") == 0) { g_mm_prio = value; return VLLM_AMD_OK; }
   if (strcmp(key, "pf_rows") == 0) { g_pf_rows = value; return VLLM_AMD_OK; }
   if (strcmp(key, "uni_decode") == 0) { g_uni_decode = value; return VLLM_AMD_OK; }
   VA_REQUIRE(false, VLLM_AMD_EINVAL, "set_tuning: unknown key %s", key);

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * NW) void scaled_mm_pp_kernel(
     out_t* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ a_scales, const float* __restrict__ b_scales,
     const out_t* __restrict__ bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-    int a_scale_numel, int b_scale_numel, int persistent, int pw, int store_mode) {
+    int a_scale_numel, int b_scale_numel, int persistent, int pw, int store_mode, int prio) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TOTAL];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -380,6 +380,9 @@ __global__ __launch_bounds__(64 * NW) void scaled_mm_pp_kernel(
   };
   set_load_tile(first);
   stage_load(0, 0);
+  // measurement (tuning "mm_prio"): a static priority for one half of the waves
+  if (prio == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+  if (prio == 2 && wave < NW / 2) __builtin_amdgcn_s_setprio(1);
   if (grp_b) run(std::true_type{});
   else run(std::false_type{});
 }
@@ -389,6 +392,7 @@ __global__ __launch_bounds__(64 * NW) void scaled_mm_pp_kernel(
 // The kernel addresses its operands with 32-bit byte offsets and writes 16-byte pieces of rows:
 // caller guarantees K % 128 == 0, K >= 256, scaled_mm_large_fits(), 16-byte aligned operands,
 // ldc % 8 == 0, N % 8 == 0, out 16-byte aligned.  variant bit 0 = stagger, bit 1 = persistent, bit 2 = stagger by a quarter block.
+int g_mm_prio = 0;    // tuning "mm_prio" (measurement): 1 = waves 4-7 at priority 1, 2 = waves 0-3
 int g_mm_store = 0;   // tuning "mm_store": see the kernel
 int g_mm_patch = 8;   // tuning "mm_patch": tile columns per super-column of the tile order (<= 1: column-major)
 int launch_scaled_mm_pp(int variant, void* out, const void* a, const void* b, const float* a_scales,
@@ -400,7 +404,7 @@ int launch_scaled_mm_pp(int variant, void* out, const void* a, const void* b, co
 #define PP_LAUNCH(T_, STG, DFR)                                                                         \
   hipLaunchKernelGGL((pp::scaled_mm_pp_kernel<T_, STG, DFR>), dim3(grid), dim3(64 * pp::NW), 0, st,      \
                      (T_*)out, (const uint8_t*)a, (const uint8_t*)b, a_scales, b_scales,            \
-                     (const T_*)bias, M, N, K, lda, ldb, ldc, asn, bsn, persistent ? 1 : 0, g_mm_patch, g_mm_store)
+                     (const T_*)bias, M, N, K, lda, ldb, ldc, asn, bsn, persistent ? 1 : 0, g_mm_patch, g_mm_store, g_mm_prio)
   if (out_dtype == VLLM_AMD_BF16) {
     if ((variant & 5) == 5) PP_LAUNCH(bf16_t, true, 2); else if (variant & 1) PP_LAUNCH(bf16_t, true, 4);
     else PP_LAUNCH(bf16_t, false, 4);
@@ -413,6 +417,49 @@ int launch_scaled_mm_pp(int variant, void* out, const void* a, const void* b, co
 }
 
 }  // namespace va
+
+// Measurement helper (bench.py prints its result beside the GEMM's fraction of the 5 PF paper peak): a loop of
+// nothing but v_mfma_scale_f32_16x16x128_f8f6f4 on pseudo-random fp8 operands held in registers, 32
+// independent accumulators per wave, 8 waves per CU on every CU -- what the matrix pipes deliver under the
+// chip's power management when no operand has to be moved (tools/mfmabench2.hip is the stand-alone form).
+namespace va {
+__global__ __launch_bounds__(512) void mfma_ceiling_kernel(float* __restrict__ sink, int iters) {
+  typedef __attribute__((ext_vector_type(4))) float f32x4;
+  typedef __attribute__((ext_vector_type(8))) int i32x8;
+  const unsigned lane = threadIdx.x;
+  i32x8 a[4], b[2];
+  unsigned h = lane * 2654435761u + 12345u;
+  auto next = [&]() {
+    unsigned w = 0;
+    for (int k = 0; k < 4; ++k) {
+      h = h * 1664525u + 1013904223u;
+      w |= ((h >> 24 & 0x80u) | ((h >> 8) % 0x48u)) << (8 * k);   // |x| <= 3.75: no NaN, no overflow
+    }
+    return (int)w;
+  };
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) a[i][j] = next();
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 8; ++j) b[i][j] = next();
+  f32x4 acc[32];
+  for (int i = 0; i < 32; ++i) acc[i] = (f32x4){0, 0, 0, 0};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+      acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i & 3], b[(i >> 2) & 1], acc[i], 0, 0, 0,
+                                                                 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  }
+  f32x4 s = acc[0];
+  for (int i = 1; i < 32; ++i) s += acc[i];
+  sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+}  // namespace va
+
+// sink: 256 * 512 floats of device memory.  FLOP of one call = 256 * 8 * iters * 32 * 2 * 16 * 16 * 128.
+extern "C" int vllm_amd_mfma_ceiling(void* sink, int iters, void* stream) {
+  VA_REQUIRE(sink != nullptr && iters > 0, VLLM_AMD_EINVAL, "mfma_ceiling: null sink or iters <= 0");
+  hipLaunchKernelGGL(va::mfma_ceiling_kernel, dim3(256), dim3(512), 0, (hipStream_t)stream, (float*)sink, iters);
+  VA_LAUNCH_CHECK("mfma_ceiling");
+  return VLLM_AMD_OK;
+}
 
 #ifdef VA_PROBES
 extern "C" int vllm_amd_probe_pp_stamps(unsigned long long* dst, int nwg) {
