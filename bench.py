@@ -22,7 +22,7 @@ any rank fails or the RCCL world is not N.  Attention shards by KV head with no 
 value = bytes of all ranks / max time.  `extra` then carries, timed over all ranks (max):
   configs4_strong   configs[4] (8 x 128k, 64q/8kv, fp8) with heads / N per rank: strong scaling
   configs3_per_gpu  configs[3] per-GPU attention shape (256 x 32k, 8q/1kv) on every rank
-  custom_all_reduce (only with VLLM_AMD_BENCH_CUSTOM_AR=1) peer-to-peer all-reduce vs RCCL, 256 KiB / 4 MiB
+  custom_all_reduce peer-to-peer all-reduce vs RCCL, 256 KiB / 4 MiB (result-checked first; VLLM_AMD_BENCH_CUSTOM_AR=0 skips)
   row_parallel_tp   configs[3] row-parallel fp8 GEMMs (K 1024 / 3584 -> 8192, M 256) + one 4 MiB
                     RCCL all-reduce (us, bus GB/s)
 
@@ -782,8 +782,9 @@ def main():
             rp = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             line.setdefault("extra", {})["row_parallel_tp"] = rp
-        if os.environ.get("VLLM_AMD_BENCH_CUSTOM_AR") == "1":
-            # opt-in: the peer-to-peer all-reduce has only run with simulated ranks on one GPU
+        if world > 1 and os.environ.get("VLLM_AMD_BENCH_CUSTOM_AR", "1") != "0":
+            # the peer-to-peer all-reduce beside RCCL: result-checked first, 2 s barrier limit, the leg stops
+            # at the first time-out or mismatch (it has only run with simulated ranks on one GPU so far)
             from vllm_amd.distributed import bench_custom_all_reduce
             try:
                 ca = bench_custom_all_reduce(device, dist)

@@ -231,8 +231,9 @@ int vllm_amd_set_workspace(void* ws, int64_t bytes, void* stream);
  * vllm_amd_scaled_mm, plus `splits`: K slices per output tile (0 = the heuristic of
  * vllm_amd_scaled_mm, 1 = never split, n = n slices, at most the number of K blocks).  A split
  * that needs more than the array holds (tiles x slices x tile bytes > 8 MiB, or > 4096 tiles)
- * returns VLLM_AMD_EUNSUPPORTED with a message; nothing is allocated, freed or synchronised (one
- * hipMemsetAsync on `stream` clears the launch's tickets).  Every call on a GPU shares that
+ * returns VLLM_AMD_EUNSUPPORTED with a message; nothing is allocated, freed or synchronised (the FIRST
+ * call on a device enqueues one hipMemsetAsync of the ticket words on `stream`; every split launch
+ * leaves its tickets at zero, so later calls enqueue nothing but the kernel).  Every call on a GPU shares that
  * GPU's array: calls that overlap on one GPU (different streams, or a replaying graph beside
  * eager calls) race -- serialise them. */
 int vllm_amd_scaled_mm_static(void* out, const void* a, const void* b,
@@ -408,20 +409,35 @@ int vllm_amd_unified_attention(
  *   kernels csrc/custom_all_reduce.cuh:296-370, one / two stage choice :561-571,
  *   python vllm/distributed/device_communicators/custom_all_reduce.py:49-305.
  * meta_ptrs[r] / ptrs[r]: rank r's signal block (vllm_amd_ar_meta_size() bytes, zeroed, followed
- * by max_size bytes of scratch) / rank r's copy of a registered buffer, as mapped into THIS
- * process.  all_reduce: out = sum over ranks of their `inp` (f32 / f16 / bf16, fp32 accumulation
- * in rank order: bit-identical on all ranks), numel * sizeof(dtype) a multiple of 16;
- * reg_buffer != NULL: inp is first copied into that registered buffer (eager mode), else inp
- * itself must be registered.  Every wait on a peer is bounded (~1 s): a late or dead peer gives
- * garbage and vllm_amd_ar_error() != 0, never a hung GPU.  Graph capture: use reg_buffer (the
- * copy is captured); get_graph_buffer_ipc_meta / register_graph_buffers have no counterpart.
+ * by scratch_bytes of scratch) / rank r's copy of a registered buffer, as mapped into THIS
+ * process.  rank_data: caller-owned device memory for the tuples of input pointers the kernels read
+ * (64 bytes per registered or graph-captured input; the reference passes an 8 MiB tensor,
+ * custom_all_reduce.py:168-176).  all_reduce: out = sum over ranks of their `inp` (f32 / f16 / bf16, fp32
+ * accumulation in rank order: bit-identical on all ranks), numel * sizeof(dtype) a multiple of 16;
+ * reg_buffer != NULL: inp is first copied into that registered buffer (eager mode), else inp itself
+ * must be registered -- or the stream is capturing: then inp is recorded, the captured kernel points at a
+ * tuple that vllm_amd_ar_register_graph_buffers fills after the capture and before the first replay
+ * (custom_all_reduce.cu:125-146: get_graph_buffer_ipc_meta on every rank, all-gather, register).
+ * Messages that take the two-stage kernel need their longest slice to fit scratch_bytes (error otherwise).
+ * Every wait on a peer is bounded in wall-clock time (30 s; vllm_amd_ar_set_timeout_ms): a dead peer never
+ * hangs the GPU, and a time-out is loud -- the output of that launch is NaN where the block gave up, and
+ * every later all_reduce of the handle returns an error (a sticky word in pinned host memory: no
+ * synchronisation; vllm_amd_ar_error reads the same word).
  * Logic-tested with simulated ranks on one GPU only; off by default. */
 int64_t vllm_amd_ar_meta_size(void);
-int vllm_amd_ar_init(void** handle, void* const* meta_ptrs, int world_size, int rank,
-                     int fully_connected);
+int vllm_amd_ar_init(void** handle, void* const* meta_ptrs, int64_t scratch_bytes, void* rank_data,
+                     int64_t rank_data_bytes, int world_size, int rank, int fully_connected);
+int vllm_amd_ar_set_timeout_ms(void* handle, int64_t ms);
 int vllm_amd_ar_register_buffer(void* handle, void* const* ptrs);
 int vllm_amd_ar_all_reduce(void* handle, const void* inp, void* out, int64_t numel, int dtype,
                            void* reg_buffer, int64_t reg_buffer_bytes, void* stream);
+/* handles_out: capacity x 64 bytes (hipIpcMemHandle_t of each recorded input's allocation), offsets_out:
+ * the inputs' offsets into them; *count = number recorded since the last registration (both outputs NULL:
+ * only the count is returned). */
+int vllm_amd_ar_get_graph_buffer_ipc_meta(void* handle, void* handles_out, int64_t* offsets_out,
+                                          int capacity, int* count);
+/* handles: [world][n][64] bytes, offsets: [world][n] -- every rank's answer to the call above. */
+int vllm_amd_ar_register_graph_buffers(void* handle, const void* handles, const int64_t* offsets, int n);
 int vllm_amd_ar_error(void* handle, int* timed_out);
 int vllm_amd_ar_dispose(void* handle);
 /* the only calls of the library that allocate, map or free memory (uncached device memory
@@ -468,6 +484,8 @@ int vllm_amd_ar_free_shared(void* ptr);
 /*                 vllm_amd_set_workspace; unsplit without one)                 */
 /* ------------------------------------------------------------------------- */
 int vllm_amd_set_tuning(const char* key, int value);
+/* current value of "pa_balance" / "mm_kernel" / "mm_splitk" (the torch layer asks before it allocates) */
+int vllm_amd_get_tuning(const char* key, int* value);
 
 #ifdef __cplusplus
 }

@@ -35,10 +35,13 @@ bad = 0
 for world in (2, 4, 8):
     metas = [torch.zeros(ms + max_size, dtype=torch.uint8, device=dev) for _ in range(world)]
     regs = [torch.empty(max_size, dtype=torch.uint8, device=dev) for _ in range(world)]
+    tables = [torch.zeros(1 << 16, dtype=torch.uint8, device=dev) for _ in range(world)]
     handles = []
     for r in range(world):
         h = C.c_void_p()
-        assert L.vllm_amd_ar_init(C.byref(h), arr([m.data_ptr() for m in metas]), world, r, 1) == 0
+        assert L.vllm_amd_ar_init(C.byref(h), arr([m.data_ptr() for m in metas]), max_size, tables[r].data_ptr(),
+                                  tables[r].numel(), world, r, 1) == 0
+        assert L.vllm_amd_ar_set_timeout_ms(h, 5000) == 0
         assert L.vllm_amd_ar_register_buffer(h, arr([b.data_ptr() for b in regs])) == 0
         handles.append(h)
     streams = [torch.cuda.Stream(device=dev) for _ in range(world)]
@@ -72,6 +75,49 @@ for world in (2, 4, 8):
                     if not torch.equal(outs[r].cpu().view(it), want.view(it)):
                         bad += 1
                         print(f"MISMATCH world={world} rank={r} {dtype} {nbytes} launch={launch}", flush=True)
+    # HIP graphs: every rank captures an all-reduce of its own UNREGISTERED tensor; the tuples the captured
+    # kernels read are filled after the capture (get_graph_buffer_ipc_meta on every rank -> "all-gather" ->
+    # register_graph_buffers), then the graphs replay concurrently, twice, with new data in place
+    numel = 96 * 1024
+    gins = [torch.zeros(numel, dtype=torch.bfloat16, device=dev) for _ in range(world)]
+    gouts = [torch.zeros(numel, dtype=torch.bfloat16, device=dev) for _ in range(world)]
+    graphs = []
+    for r in range(world):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=streams[r]):
+            rc = L.vllm_amd_ar_all_reduce(handles[r], gins[r].data_ptr(), gouts[r].data_ptr(), numel, 2, None, 0,
+                                          streams[r].cuda_stream)
+            assert rc == 0, L.vllm_amd_last_error()
+        graphs.append(gr)
+    hb, ob = b"", []
+    for r in range(world):
+        n = C.c_int(0)
+        hbuf = (C.c_ubyte * 64)(); obuf = (C.c_int64 * 1)()
+        assert L.vllm_amd_ar_get_graph_buffer_ipc_meta(handles[r], hbuf, obuf, 1, C.byref(n)) == 0, L.vllm_amd_last_error()
+        assert n.value == 1
+        hb += bytes(hbuf); ob.append(obuf[0])
+    for r in range(world):
+        rc = L.vllm_amd_ar_register_graph_buffers(handles[r], (C.c_ubyte * len(hb)).from_buffer_copy(hb),
+                                                  (C.c_int64 * world)(*ob), 1)
+        assert rc == 0, L.vllm_amd_last_error()
+    g = torch.Generator().manual_seed(world)
+    for rep in range(2):
+        xs = [torch.randn(numel, generator=g).to(torch.bfloat16) for _ in range(world)]
+        acc = xs[0].float().clone()
+        for x in xs[1:]:
+            acc += x.float()
+        for r in range(world):
+            gins[r].copy_(xs[r])
+        torch.cuda.synchronize()
+        for r in range(world):
+            with torch.cuda.stream(streams[r]):
+                graphs[r].replay()
+        torch.cuda.synchronize()
+        for r in range(world):
+            if not torch.equal(gouts[r].cpu(), acc.to(torch.bfloat16)):
+                bad += 1
+                print(f"GRAPH MISMATCH world={world} rank={r} rep={rep}", flush=True)
+    del graphs
     for h in handles:
         L.vllm_amd_ar_dispose(h)
     print(f"world {world} done", flush=True)
@@ -96,16 +142,57 @@ def test_unregistered_buffer_and_bad_sizes_are_errors():
     L = _lib.lib
     dev = torch.device("cuda", 0)
     ms = L.vllm_amd_ar_meta_size()
-    metas = [torch.zeros(ms + 1024, dtype=torch.uint8, device=dev) for _ in range(2)]
+    metas = [torch.zeros(ms + 1024, dtype=torch.uint8, device=dev) for _ in range(4)]
+    table = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    mp = _arr([m.data_ptr() for m in metas])
     h = C.c_void_p()
-    assert L.vllm_amd_ar_init(C.byref(h), _arr([m.data_ptr() for m in metas]), 3, 0, 1) != 0
+    assert L.vllm_amd_ar_init(C.byref(h), mp, 1024, table.data_ptr(), 4096, 3, 0, 1) != 0
     assert b"(2,4,6,8)" in L.vllm_amd_last_error()
-    assert L.vllm_amd_ar_init(C.byref(h), _arr([m.data_ptr() for m in metas]), 2, 0, 1) == 0
+    assert L.vllm_amd_ar_init(C.byref(h), _arr([metas[0].data_ptr(), None]), 1024, table.data_ptr(), 4096, 2, 0, 1) != 0
+    assert b"null meta pointer" in L.vllm_amd_last_error()
+    assert L.vllm_amd_ar_init(C.byref(h), mp, 1024, None, 0, 2, 0, 1) != 0
+    assert b"rank-data table" in L.vllm_amd_last_error()
+    assert L.vllm_amd_ar_init(C.byref(h), mp, 1024, table.data_ptr(), 4096, 2, 0, 1) == 0
     x = torch.zeros(64, dtype=torch.bfloat16, device=dev)
     assert L.vllm_amd_ar_all_reduce(h, x.data_ptr(), x.data_ptr(), 64, 2, None, 0, None) != 0
     assert b"is not registered" in L.vllm_amd_last_error()
     assert L.vllm_amd_ar_all_reduce(h, x.data_ptr(), x.data_ptr(), 3, 2, None, 0, None) != 0
     assert b"multiple of 16 bytes" in L.vllm_amd_last_error()
+    assert L.vllm_amd_ar_all_reduce(h, x.data_ptr(), x.data_ptr(), 64, 7, None, 0, None) != 0   # no such dtype
+    assert b"float32, float16 and bfloat16" in L.vllm_amd_last_error()
+    L.vllm_amd_ar_dispose(h)
+    # four ranks, 1024 bytes of scratch: a 1 MiB message takes the two-stage kernel, whose slice does not fit
+    assert L.vllm_amd_ar_init(C.byref(h), mp, 1024, table.data_ptr(), 4096, 4, 0, 1) == 0
+    big = torch.zeros(1 << 19, dtype=torch.bfloat16, device=dev)
+    assert L.vllm_amd_ar_register_buffer(h, _arr([big.data_ptr()] * 4)) == 0
+    assert L.vllm_amd_ar_all_reduce(h, big.data_ptr(), big.data_ptr(), big.numel(), 2, None, 0, None) != 0
+    assert b"bytes of scratch" in L.vllm_amd_last_error()
+    L.vllm_amd_ar_dispose(h)
+
+
+def test_missing_peer_times_out_loudly():
+    """Rank 0 of a world of 2 whose peer never launches: the bounded barrier gives up after the configured
+    time (200 ms here), the output is NaN (not a plausible partial sum), vllm_amd_ar_error says so without a
+    device synchronisation, and every later call of the handle is refused."""
+    from vllm_amd import _lib
+    L = _lib.lib
+    dev = torch.device("cuda", 0)
+    ms = L.vllm_amd_ar_meta_size()
+    metas = [torch.zeros(ms + 4096, dtype=torch.uint8, device=dev) for _ in range(2)]
+    table = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    h = C.c_void_p()
+    assert L.vllm_amd_ar_init(C.byref(h), _arr([m.data_ptr() for m in metas]), 4096, table.data_ptr(), 4096, 2, 0, 1) == 0
+    assert L.vllm_amd_ar_set_timeout_ms(h, 200) == 0
+    ins = [torch.ones(4096, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+    assert L.vllm_amd_ar_register_buffer(h, _arr([t.data_ptr() for t in ins])) == 0
+    out = torch.zeros(4096, dtype=torch.bfloat16, device=dev)
+    assert L.vllm_amd_ar_all_reduce(h, ins[0].data_ptr(), out.data_ptr(), 4096, 2, None, 0, None) == 0
+    torch.cuda.synchronize()
+    assert out.isnan().all()
+    t = C.c_int(0)
+    assert L.vllm_amd_ar_error(h, C.byref(t)) == 0 and t.value == 1
+    assert L.vllm_amd_ar_all_reduce(h, ins[0].data_ptr(), out.data_ptr(), 4096, 2, None, 0, None) != 0
+    assert b"did not arrive" in L.vllm_amd_last_error()
     L.vllm_amd_ar_dispose(h)
 
 
@@ -132,6 +219,31 @@ for numel in (256, 65536, 1 << 20):
     out = tensor_model_parallel_all_reduce(xs[rank].to(dev), dist, None, custom_ar=ar)
     torch.cuda.synchronize()
     ok = ok and torch.equal(out.cpu(), want)
+# HIP graph: the input is used in place; its address is registered on both ranks (real IPC handles of the
+# torch allocation + offset) when the capture context ends; replays with new data in the same tensor
+ar.set_timeout_ms(5000)
+xg = torch.zeros(8192, dtype=torch.bfloat16, device=dev)
+st = torch.cuda.Stream()
+with ar.capture():
+    with torch.cuda.stream(st):
+        assert ar.custom_all_reduce(xg) is not None            # warm-up inside the context: allocation only
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            og = ar.custom_all_reduce(xg)
+torch.cuda.synchronize()
+if not ar.timed_out():
+    for rep in range(2):
+        g = torch.Generator().manual_seed(77 + rep)
+        xs = [torch.randn(8192, generator=g).to(torch.bfloat16) for _ in range(world)]
+        xg.copy_(xs[rank].to(dev))
+        torch.cuda.synchronize()
+        dist.barrier()
+        with torch.cuda.stream(st):
+            gr.replay()
+        torch.cuda.synchronize()
+        wantg = (xs[0].float() + xs[1].float()).to(torch.bfloat16)
+        ok = ok and torch.equal(og.cpu(), wantg)
+        dist.barrier()
 timed_out = ar.timed_out()
 assert ar.should_custom_ar(torch.empty(8, dtype=torch.bfloat16, device=dev))
 assert not ar.should_custom_ar(torch.empty(3, dtype=torch.bfloat16, device=dev))

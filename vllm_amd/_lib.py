@@ -66,7 +66,11 @@ SIGNATURES = {
         _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _f, _i, _i, _vp,
         _vp, _vp, _i, _i, _i, _vp],
     "vllm_amd_set_tuning": [C.c_char_p, _i],
-    "vllm_amd_ar_init": [C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i],
+    "vllm_amd_get_tuning": [C.c_char_p, C.POINTER(_i)],
+    "vllm_amd_ar_init": [C.POINTER(_vp), C.POINTER(_vp), _i64, _vp, _i64, _i, _i, _i],
+    "vllm_amd_ar_set_timeout_ms": [_vp, _i64],
+    "vllm_amd_ar_get_graph_buffer_ipc_meta": [_vp, _vp, C.POINTER(_i64), _i, C.POINTER(_i)],
+    "vllm_amd_ar_register_graph_buffers": [_vp, _vp, C.POINTER(_i64), _i],
     "vllm_amd_ar_register_buffer": [_vp, C.POINTER(_vp)],
     "vllm_amd_ar_all_reduce": [_vp, _vp, _vp, _i64, _i, _vp, _i64, _vp],
     "vllm_amd_ar_error": [_vp, C.POINTER(_i)],

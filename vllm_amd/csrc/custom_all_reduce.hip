@@ -12,29 +12,42 @@
 //     scratch (reduce-scatter by reads), barrier, then gathers the NG reduced slices from the
 //     peers' scratch: 2/NG of the one-stage link traffic.
 // Ranks synchronise through flag words in each other's memory: block b of rank r writes its
-// launch number into peer p's `start[b][r]` and spins on its own `start[b][p]`.  Every spin is
-// BOUNDED: after kSpinLimit polls the block records a time-out in its signal block and goes on
-// (the result is then garbage and vllm_amd_ar_error reports it) -- a dead or late peer can never
-// hang the GPU.
+// launch number into peer p's `start[b][r]` and spins on its own `start[b][p]` until that word has
+// reached the launch number (wrap-safe >=: a rank that arrives late catches up instead of missing
+// the word its peer has already moved on from).  Every spin is BOUNDED in wall-clock time
+// (s_memrealtime; 30 s unless vllm_amd_ar_set_timeout_ms says otherwise -- generous: a peer may be
+// busy with host work, a graph capture, a start-up) so that a dead peer can never hang the GPU, and a
+// time-out is LOUD: the block overwrites its part of `out` with NaN, and a sticky word in pinned host
+// memory makes every later vllm_amd_ar_all_reduce of the handle return an error without synchronising.
 //
 // Nothing is allocated inside all_reduce; buffers come from the caller (the helpers at the end
 // wrap hipExtMallocWithFlags / hipIpc* for the Python side, as the reference's
 // allocate_shared_buffer_and_handle / open_mem_handle do).
 //
+// HIP graphs: an input met under stream capture needs no copy into a pre-registered buffer -- the
+// captured kernel points at a tuple of the caller's rank-data table that is filled after the capture
+// (vllm_amd_ar_get_graph_buffer_ipc_meta / vllm_amd_ar_register_graph_buffers, as the reference's
+// custom_all_reduce.cu:125-146).
+//
 // STATUS: logic-tested with simulated ranks (one process, one stream per rank, one GPU) and with
 // two processes sharing one GPU through IPC handles; never run across GPUs (the development box
-// has one).  Off by default: tensor_model_parallel_all_reduce uses RCCL unless asked otherwise.
+// has one).  Off by default: tensor_model_parallel_all_reduce uses RCCL unless asked otherwise;
+// `bench.py --gpus N` runs it beside RCCL, result-checked first.
 #include "common.cuh"
 
+#include <string.h>
+
 #include <mutex>
+#include <string>
 #include <unordered_map>
+#include <vector>
 
 namespace va {
 
 constexpr int AR_MAX_RANKS = 8;
 constexpr int AR_MAX_BLOCKS = 64;
 constexpr int AR_THREADS = 512;
-constexpr unsigned kSpinLimit = 1u << 20;   // ~1 s of polling
+constexpr int64_t kDefaultTimeoutMs = 30000;
 
 struct ArSignal {
   alignas(128) uint32_t start[AR_MAX_BLOCKS][AR_MAX_RANKS];
@@ -53,13 +66,21 @@ __device__ __forceinline__ uint32_t ld_sys(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// All NG ranks' block b meet.  WHICH selects the flag array; FENCE: what this rank wrote before
-// the barrier is visible to the peers after it (release before the flag, acquire after the spin).
-template <int NG, int WHICH, bool FENCE>
-__device__ __forceinline__ void ar_barrier(const ArPeers& sg, ArSignal* self, int rank, uint32_t flag) {
+struct ArCtl {
+  unsigned long long timeout_ticks;   // 100 MHz ticks (s_memrealtime)
+  uint32_t* host_err;                 // pinned host word, sticky
+};
+
+// All NG ranks' block b meet.  WHICH selects the flag array; REL: what this rank wrote before the
+// barrier is visible to the peers after it (release before the flag); ACQ: what the peers wrote before
+// theirs is visible here (acquire behind the spin: nothing cached of the peers' memory survives it).
+// Returns nothing; a time-out sets *bad (LDS), the signal block's word and the host's.
+template <int NG, int WHICH, bool REL, bool ACQ>
+__device__ __forceinline__ void ar_barrier(const ArPeers& sg, ArSignal* self, int rank, uint32_t flag,
+                                           const ArCtl& ctl, int* bad) {
   if constexpr (WHICH != 0) __syncthreads();   // every thread of the block is done with the phase before
   if (threadIdx.x < NG) {
-    if constexpr (FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if constexpr (REL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     ArSignal* peer = (ArSignal*)sg.p[threadIdx.x];
     uint32_t* theirs = WHICH == 0 ? &peer->start[blockIdx.x][rank]
                      : WHICH == 1 ? &peer->mid[blockIdx.x][rank] : &peer->end[blockIdx.x][rank];
@@ -67,15 +88,19 @@ __device__ __forceinline__ void ar_barrier(const ArPeers& sg, ArSignal* self, in
                          : WHICH == 1 ? &self->mid[blockIdx.x][threadIdx.x]
                                       : &self->end[blockIdx.x][threadIdx.x];
     st_sys(theirs, flag);
-    unsigned polls = 0;
-    while (ld_sys(mine) != flag) {
-      if (++polls > kSpinLimit) {   // the exit every wave reaches
-        st_sys(&self->timed_out, 1u);
-        break;
+    if ((int32_t)(ld_sys(mine) - flag) < 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while ((int32_t)(ld_sys(mine) - flag) < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > ctl.timeout_ticks) {   // the exit every wave reaches
+          st_sys(&self->timed_out, 1u);
+          st_sys(ctl.host_err, 1u);
+          *bad = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
       }
-      __builtin_amdgcn_s_sleep(1);
     }
-    if constexpr (FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if constexpr (ACQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
   __syncthreads();
 }
@@ -104,23 +129,39 @@ __device__ __forceinline__ uint4 ar_sum(const ArPeers& bufs, int64_t i) {
   return o;
 }
 
-// nvec = message size in 16-byte vectors
+// nvec = message size in 16-byte vectors; bufs_p: the tuple of the ranks' input pointers, in device
+// memory (the caller's rank-data table: filled at registration, for graph-captured launches AFTER the
+// capture -- vllm_amd_ar_register_graph_buffers)
 template <typename T, int NG>
-__global__ __launch_bounds__(AR_THREADS) void ar_one_stage_kernel(ArPeers bufs, ArPeers sg, ArSignal* self,
-                                                                  uint4* __restrict__ out, int rank,
-                                                                  int64_t nvec) {
+__global__ __launch_bounds__(AR_THREADS) void ar_one_stage_kernel(const ArPeers* __restrict__ bufs_p, ArPeers sg,
+                                                                  ArSignal* self, uint4* __restrict__ out,
+                                                                  int rank, int64_t nvec, ArCtl ctl) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  const ArPeers bufs = *bufs_p;
   const uint32_t flag = self->epoch[blockIdx.x] + 1;
-  ar_barrier<NG, 0, false>(sg, self, rank, flag);    // every peer's input is complete (earlier kernels)
+  // every peer's input is complete (its earlier kernels released it at their end) -- and nothing this
+  // GPU may still cache of those buffers from the previous launch is served again (acquire)
+  ar_barrier<NG, 0, false, true>(sg, self, rank, flag, ctl, &bad);
   for (int64_t i = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * AR_THREADS)
     out[i] = ar_sum<T, NG>(bufs, i);
-  ar_barrier<NG, 2, false>(sg, self, rank, flag);    // nobody overwrites an input a peer still reads
+  ar_barrier<NG, 2, false, false>(sg, self, rank, flag, ctl, &bad);    // nobody overwrites an input a peer still reads
   if (threadIdx.x == 0) self->epoch[blockIdx.x] = flag;
+  if (bad) {   // a peer never arrived: this block's outputs are not a sum -- make that visible (NaN in every dtype)
+    for (int64_t i = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * AR_THREADS)
+      out[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+  }
 }
 
 template <typename T, int NG>
-__global__ __launch_bounds__(AR_THREADS) void ar_two_stage_kernel(ArPeers bufs, ArPeers sg, ArSignal* self,
-                                                                  uint4* __restrict__ out, int rank,
-                                                                  int64_t nvec) {
+__global__ __launch_bounds__(AR_THREADS) void ar_two_stage_kernel(const ArPeers* __restrict__ bufs_p, ArPeers sg,
+                                                                  ArSignal* self, uint4* __restrict__ out,
+                                                                  int rank, int64_t nvec, ArCtl ctl) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  const ArPeers bufs = *bufs_p;
   const uint32_t flag = self->epoch[blockIdx.x] + 1;
   const int64_t part = nvec / NG;   // slice r = [r part, (r+1) part), the last one takes the rest
   auto slice_begin = [&](int r) { return (int64_t)r * part; };
@@ -129,14 +170,14 @@ __global__ __launch_bounds__(AR_THREADS) void ar_two_stage_kernel(ArPeers bufs, 
   ArPeers tmp;
 #pragma unroll
   for (int r = 0; r < NG; ++r) tmp.p[r] = (char*)sg.p[r] + sizeof(ArSignal);
-  ar_barrier<NG, 0, false>(sg, self, rank, flag);
+  ar_barrier<NG, 0, false, true>(sg, self, rank, flag, ctl, &bad);
   {
     uint4* mine = (uint4*)tmp.p[rank];
     const int64_t b = slice_begin(rank), e = slice_end(rank);
     for (int64_t i = b + (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < e; i += (int64_t)gridDim.x * AR_THREADS)
       mine[i - b] = ar_sum<T, NG>(bufs, i);
   }
-  ar_barrier<NG, 1, true>(sg, self, rank, flag);     // the reduced slices are visible to the peers
+  ar_barrier<NG, 1, true, true>(sg, self, rank, flag, ctl, &bad);     // the reduced slices are visible to the peers
   // gather: block b of every rank reduced the same positions of its slice, so block b only reads
   // what the peers' block b wrote -- the barrier above is per block
 #pragma unroll
@@ -147,35 +188,62 @@ __global__ __launch_bounds__(AR_THREADS) void ar_two_stage_kernel(ArPeers bufs, 
     for (int64_t i = b + (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < e; i += (int64_t)gridDim.x * AR_THREADS)
       out[i] = src[i - b];
   }
-  ar_barrier<NG, 2, false>(sg, self, rank, flag);
+  ar_barrier<NG, 2, false, false>(sg, self, rank, flag, ctl, &bad);
   if (threadIdx.x == 0) self->epoch[blockIdx.x] = flag;
+  if (bad) {
+#pragma unroll
+    for (int r = 0; r < NG; ++r) {
+      const int64_t b = slice_begin(r), e = slice_end(r);
+      for (int64_t i = b + (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < e; i += (int64_t)gridDim.x * AR_THREADS)
+        out[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    }
+  }
 }
 
 struct ArState {
   int world = 0, rank = 0;
   bool fully_connected = false;
   ArPeers sg;
-  std::unordered_map<const void*, ArPeers> buffers;
+  int64_t scratch_bytes = 0;                 // behind every signal block
+  ArPeers* table = nullptr;                  // caller's rank-data table (device memory)
+  int64_t table_slots = 0, table_used = 0;
+  std::unordered_map<const void*, const ArPeers*> buffers;   // registered input -> its tuple in the table
+  std::vector<void*> graph_unreg;            // inputs met under stream capture, tuples still to be filled
+  std::unordered_map<std::string, void*> opened;             // IPC handle bytes -> mapping in this process
+  uint32_t* host_err = nullptr;              // pinned, mapped: sticky time-out word
+  uint32_t* host_err_dev = nullptr;
+  int64_t timeout_ms = kDefaultTimeoutMs;
   std::mutex mu;
 };
 
+// IPC handles this process handed out (vllm_amd_ar_get_graph_buffer_ipc_meta) -> the allocation's base:
+// ranks that live in ONE process (the single-GPU simulation of the tests) find each other's buffers
+// here; hipIpcOpenMemHandle refuses a handle of the opening process itself.
+static std::mutex g_ipc_mu;
+static std::unordered_map<std::string, void*> g_ipc_local;
+
+static bool ar_one_stage(const ArState* st, int64_t bytes) {
+  // custom_all_reduce.cuh:561-571: two ranks always one stage; fully connected: one stage below
+  // 512 KiB (<= 4 ranks) / 256 KiB (<= 8 ranks), two stages above
+  return st->world == 2 || (st->world <= 4 && bytes < 512 * 1024) || bytes < 256 * 1024;
+}
+
 template <typename T>
-static void ar_launch(ArState* st, const ArPeers& bufs, void* out, int64_t nvec, int64_t bytes, hipStream_t s) {
+static void ar_launch(ArState* st, const ArPeers* bufs, void* out, int64_t nvec, int64_t bytes, hipStream_t s) {
   ArSignal* self = (ArSignal*)st->sg.p[st->rank];
   int64_t blocks = (nvec + AR_THREADS - 1) / AR_THREADS;
   if (blocks > AR_MAX_BLOCKS) blocks = AR_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
-  // custom_all_reduce.cuh:561-571: two ranks always one stage; fully connected: one stage below
-  // 512 KiB (<= 4 ranks) / 256 KiB (<= 8 ranks), two stages above
-  const bool one = st->world == 2 || (st->world <= 4 && bytes < 512 * 1024) || bytes < 256 * 1024;
+  const bool one = ar_one_stage(st, bytes);
+  const ArCtl ctl{(unsigned long long)st->timeout_ms * 100000ull, st->host_err_dev};
 #define AR_KL(NG)                                                                                   \
   do {                                                                                              \
     if (one)                                                                                        \
       hipLaunchKernelGGL((ar_one_stage_kernel<T, NG>), dim3((unsigned)blocks), dim3(AR_THREADS), 0, \
-                         s, bufs, st->sg, self, (uint4*)out, st->rank, nvec);                       \
+                         s, bufs, st->sg, self, (uint4*)out, st->rank, nvec, ctl);                  \
     else                                                                                            \
       hipLaunchKernelGGL((ar_two_stage_kernel<T, NG>), dim3((unsigned)blocks), dim3(AR_THREADS), 0, \
-                         s, bufs, st->sg, self, (uint4*)out, st->rank, nvec);                       \
+                         s, bufs, st->sg, self, (uint4*)out, st->rank, nvec, ctl);                  \
   } while (0)
   switch (st->world) {
     case 2: AR_KL(2); break;
@@ -192,19 +260,52 @@ using namespace va;
 
 extern "C" int64_t vllm_amd_ar_meta_size(void) { return (int64_t)sizeof(ArSignal); }
 
-extern "C" int vllm_amd_ar_init(void** handle, void* const* meta_ptrs, int world_size, int rank,
-                                int fully_connected) {
+extern "C" int vllm_amd_ar_init(void** handle, void* const* meta_ptrs, int64_t scratch_bytes, void* rank_data,
+                                int64_t rank_data_bytes, int world_size, int rank, int fully_connected) {
   VA_REQUIRE(handle && meta_ptrs, VLLM_AMD_EINVAL, "ar_init: null pointer");
   VA_REQUIRE(world_size == 2 || world_size == 4 || world_size == 6 || world_size == 8, VLLM_AMD_EUNSUPPORTED,
              "custom allreduce only supports num gpus in (2,4,6,8). Actual num gpus = %d", world_size);
   VA_REQUIRE(world_size % 2 == 0 && rank >= 0 && rank < world_size, VLLM_AMD_EINVAL, "invalid rank passed in");
   VA_REQUIRE(world_size == 2 || fully_connected, VLLM_AMD_EUNSUPPORTED,
              "custom allreduce: more than two ranks need fully connected links");
+  for (int i = 0; i < world_size; ++i) VA_REQUIRE(meta_ptrs[i] != nullptr, VLLM_AMD_EINVAL, "ar_init: null meta pointer");
+  VA_REQUIRE(scratch_bytes >= 0, VLLM_AMD_EINVAL, "ar_init: negative scratch size");
+  VA_REQUIRE(rank_data != nullptr && rank_data_bytes >= (int64_t)sizeof(ArPeers) && (((uintptr_t)rank_data) & 15) == 0,
+             VLLM_AMD_EINVAL, "ar_init: the rank-data table needs at least %zu bytes of 16-byte aligned device memory",
+             sizeof(ArPeers));
+  uint32_t* herr = nullptr;
+  hipError_t e = hipHostMalloc((void**)&herr, 64, hipHostMallocMapped);
+  if (e != hipSuccess) return hip_fail(e, "ar_init: hipHostMalloc");
+  *herr = 0;
+  uint32_t* herr_dev = nullptr;
+  e = hipHostGetDevicePointer((void**)&herr_dev, herr, 0);
+  if (e != hipSuccess) { (void)hipHostFree(herr); return hip_fail(e, "ar_init: hipHostGetDevicePointer"); }
   ArState* st = new ArState();
   st->world = world_size; st->rank = rank; st->fully_connected = fully_connected != 0;
   for (int i = 0; i < AR_MAX_RANKS; ++i) st->sg.p[i] = i < world_size ? meta_ptrs[i] : nullptr;
-  for (int i = 0; i < world_size; ++i) VA_REQUIRE(meta_ptrs[i] != nullptr, VLLM_AMD_EINVAL, "ar_init: null meta pointer");
+  st->scratch_bytes = scratch_bytes;
+  st->table = (ArPeers*)rank_data;
+  st->table_slots = rank_data_bytes / (int64_t)sizeof(ArPeers);
+  st->host_err = herr; st->host_err_dev = herr_dev;
   *handle = st;
+  return VLLM_AMD_OK;
+}
+
+extern "C" int vllm_amd_ar_set_timeout_ms(void* handle, int64_t ms) {
+  VA_REQUIRE(handle && ms > 0 && ms <= 3600000, VLLM_AMD_EINVAL, "ar_set_timeout_ms: 1 ms .. 1 h");
+  ((ArState*)handle)->timeout_ms = ms;
+  return VLLM_AMD_OK;
+}
+
+// one tuple into the caller's table (synchronous: registration time)
+static int ar_put_tuple(ArState* st, const ArPeers& p, const ArPeers** where) {
+  VA_REQUIRE(st->table_used < st->table_slots, VLLM_AMD_EUNSUPPORTED,
+             "Rank data buffer is overflowed by %lld", (long long)(st->table_used + 1 - st->table_slots));
+  ArPeers* slot = st->table + st->table_used;
+  hipError_t e = hipMemcpy(slot, &p, sizeof(ArPeers), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return hip_fail(e, "custom allreduce: hipMemcpy of a pointer tuple");
+  st->table_used += 1;
+  *where = slot;
   return VLLM_AMD_OK;
 }
 
@@ -214,7 +315,12 @@ extern "C" int vllm_amd_ar_register_buffer(void* handle, void* const* ptrs) {
   ArPeers p;
   for (int i = 0; i < AR_MAX_RANKS; ++i) p.p[i] = i < st->world ? ptrs[i] : nullptr;
   std::lock_guard<std::mutex> lk(st->mu);
-  st->buffers[ptrs[st->rank]] = p;
+  VA_REQUIRE(st->graph_unreg.empty(), VLLM_AMD_EINVAL,
+             "ar_register_buffer: graph buffers met under capture are waiting for vllm_amd_ar_register_graph_buffers");
+  const ArPeers* where = nullptr;
+  const int rc = ar_put_tuple(st, p, &where);
+  if (rc != VLLM_AMD_OK) return rc;
+  st->buffers[ptrs[st->rank]] = where;
   return VLLM_AMD_OK;
 }
 
@@ -222,14 +328,26 @@ extern "C" int vllm_amd_ar_all_reduce(void* handle, const void* inp, void* out, 
                                       void* reg_buffer, int64_t reg_buffer_bytes, void* stream) {
   VA_REQUIRE(handle && inp && out, VLLM_AMD_EINVAL, "ar_all_reduce: null pointer");
   ArState* st = (ArState*)handle;
+  VA_REQUIRE(dtype == VLLM_AMD_F32 || dtype == VLLM_AMD_F16 || dtype == VLLM_AMD_BF16, VLLM_AMD_EUNSUPPORTED,
+             "custom allreduce only supports float32, float16 and bfloat16");
+  VA_REQUIRE(*(volatile uint32_t*)st->host_err == 0, VLLM_AMD_EHIP,
+             "custom allreduce: a peer did not arrive within %lld ms in an earlier all-reduce of this handle (its "
+             "output was filled with NaN); the handle is unusable", (long long)st->timeout_ms);
   const int es = dtype_size(dtype);
-  VA_REQUIRE(es > 0, VLLM_AMD_EUNSUPPORTED, "custom allreduce only supports float32, float16 and bfloat16");
   const int64_t bytes = numel * es;
   VA_REQUIRE(numel >= 0 && bytes % 16 == 0, VLLM_AMD_EINVAL,
              "custom allreduce currently requires input length to be multiple of 16 bytes");
   VA_REQUIRE((((uintptr_t)inp) & 15) == 0 && (((uintptr_t)out) & 15) == 0, VLLM_AMD_EINVAL,
              "ar_all_reduce: buffers must be 16-byte aligned");
   if (numel == 0) return VLLM_AMD_OK;
+  const int64_t nvec = bytes / 16;
+  if (!ar_one_stage(st, bytes)) {
+    // the two-stage kernel parks a rank's reduced slice (the last one is the longest) behind its signal block
+    const int64_t slice = (nvec - (st->world - 1) * (nvec / st->world)) * 16;
+    VA_REQUIRE(slice <= st->scratch_bytes, VLLM_AMD_EINVAL,
+               "ar_all_reduce: %lld bytes need %lld bytes of scratch behind the signal block, the handle has %lld",
+               (long long)bytes, (long long)slice, (long long)st->scratch_bytes);
+  }
   hipStream_t s = (hipStream_t)stream;
   const void* src = inp;
   if (reg_buffer) {   // eager mode: stage the input in the pre-registered buffer (custom_all_reduce.cu:78-84)
@@ -238,14 +356,25 @@ extern "C" int vllm_amd_ar_all_reduce(void* handle, const void* inp, void* out, 
     if (e != hipSuccess) return hip_fail(e, "ar_all_reduce: hipMemcpyAsync");
     src = reg_buffer;
   }
-  ArPeers bufs;
+  const ArPeers* bufs = nullptr;
   {
     std::lock_guard<std::mutex> lk(st->mu);
     auto it = st->buffers.find(src);
-    VA_REQUIRE(it != st->buffers.end(), VLLM_AMD_EINVAL, "buffer address %p is not registered!", src);
-    bufs = it->second;
+    if (it != st->buffers.end()) {
+      bufs = it->second;
+    } else {
+      // custom_all_reduce.cuh:537-545: under stream capture an unregistered input gets the next free
+      // tuple of the table; its contents arrive with vllm_amd_ar_register_graph_buffers, before any replay
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+      VA_REQUIRE(cs == hipStreamCaptureStatusActive, VLLM_AMD_EINVAL, "buffer address %p is not registered!", src);
+      const int64_t at = st->table_used + (int64_t)st->graph_unreg.size();
+      VA_REQUIRE(at < st->table_slots, VLLM_AMD_EUNSUPPORTED, "Rank data buffer is overflowed by %lld",
+                 (long long)(at + 1 - st->table_slots));
+      bufs = st->table + at;
+      st->graph_unreg.push_back(const_cast<void*>(src));
+    }
   }
-  const int64_t nvec = bytes / 16;
   if (dtype == VLLM_AMD_F32) ar_launch<float>(st, bufs, out, nvec, bytes, s);
   else if (dtype == VLLM_AMD_F16) ar_launch<f16_t>(st, bufs, out, nvec, bytes, s);
   else ar_launch<bf16_t>(st, bufs, out, nvec, bytes, s);
@@ -253,19 +382,99 @@ extern "C" int vllm_amd_ar_all_reduce(void* handle, const void* inp, void* out, 
   return VLLM_AMD_OK;
 }
 
-// 1 in *timed_out if any barrier of this rank gave up waiting since init (synchronises the device).
+// custom_all_reduce.cu:125-131, .cuh:440-458: the inputs met under capture since the last registration, as
+// (IPC handle of the allocation, offset into it) pairs.  handles_out: capacity x 64 bytes.
+extern "C" int vllm_amd_ar_get_graph_buffer_ipc_meta(void* handle, void* handles_out, int64_t* offsets_out,
+                                                     int capacity, int* count) {
+  VA_REQUIRE(handle && count, VLLM_AMD_EINVAL, "ar_get_graph_buffer_ipc_meta: null pointer");
+  ArState* st = (ArState*)handle;
+  std::lock_guard<std::mutex> lk(st->mu);
+  const int n = (int)st->graph_unreg.size();
+  *count = n;
+  if (n == 0 || (!handles_out && !offsets_out)) return VLLM_AMD_OK;   // (NULL outputs: only the count)
+  VA_REQUIRE(handles_out && offsets_out && capacity >= n, VLLM_AMD_EINVAL,
+             "ar_get_graph_buffer_ipc_meta: %d buffers, room for %d", n, capacity);
+  for (int i = 0; i < n; ++i) {
+    void* ptr = st->graph_unreg[i];
+    void* base = nullptr;
+    // (the handle names the whole allocation: share its base, carry the offset)
+    hipError_t e = hipPointerGetAttribute(&base, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, (hipDeviceptr_t)ptr);
+    if (e != hipSuccess || !base) return hip_fail(e, "failed to get pointer attr");
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, base);
+    if (e != hipSuccess) return hip_fail(e, "ar_get_graph_buffer_ipc_meta: hipIpcGetMemHandle");
+    memcpy((char*)handles_out + (size_t)i * sizeof(h), &h, sizeof(h));
+    offsets_out[i] = (char*)ptr - (char*)base;
+    std::lock_guard<std::mutex> lg(g_ipc_mu);
+    g_ipc_local[std::string((const char*)&h, sizeof(h))] = base;
+  }
+  return VLLM_AMD_OK;
+}
+
+// custom_all_reduce.cu:134-146, .cuh:489-514: handles / offsets of ALL ranks ([world][n][64] bytes,
+// [world][n]) for the n inputs this rank met under capture (every rank captured the same sequence):
+// opens the peers' allocations and fills the n tuples the captured kernels point at.
+extern "C" int vllm_amd_ar_register_graph_buffers(void* handle, const void* handles, const int64_t* offsets, int n) {
+  VA_REQUIRE(handle, VLLM_AMD_EINVAL, "ar_register_graph_buffers: null handle");
+  ArState* st = (ArState*)handle;
+  std::lock_guard<std::mutex> lk(st->mu);
+  VA_REQUIRE(n == (int)st->graph_unreg.size(), VLLM_AMD_EINVAL,
+             "ar_register_graph_buffers: %d buffers given, %zu met under capture", n, st->graph_unreg.size());
+  if (n == 0) return VLLM_AMD_OK;
+  VA_REQUIRE(handles && offsets, VLLM_AMD_EINVAL, "ar_register_graph_buffers: null pointer");
+  VA_REQUIRE(st->table_used + n <= st->table_slots, VLLM_AMD_EUNSUPPORTED, "Rank data buffer is overflowed by %lld",
+             (long long)(st->table_used + n - st->table_slots));
+  std::vector<ArPeers> tuples((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < AR_MAX_RANKS; ++j) tuples[i].p[j] = nullptr;
+    for (int j = 0; j < st->world; ++j) {
+      if (j == st->rank) { tuples[i].p[j] = st->graph_unreg[i]; continue; }
+      const char* hb = (const char*)handles + ((size_t)j * n + i) * sizeof(hipIpcMemHandle_t);
+      const std::string key(hb, sizeof(hipIpcMemHandle_t));
+      void* base = nullptr;
+      {
+        std::lock_guard<std::mutex> lg(g_ipc_mu);
+        auto it = g_ipc_local.find(key);
+        if (it != g_ipc_local.end()) base = it->second;   // a rank of this very process
+      }
+      if (!base) {
+        auto it = st->opened.find(key);
+        if (it != st->opened.end()) base = it->second;
+      }
+      if (!base) {
+        hipIpcMemHandle_t h;
+        memcpy(&h, hb, sizeof(h));
+        hipError_t e = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return hip_fail(e, "ar_register_graph_buffers: hipIpcOpenMemHandle");
+        st->opened[key] = base;
+      }
+      tuples[i].p[j] = (char*)base + offsets[(size_t)j * n + i];
+    }
+  }
+  hipError_t e = hipMemcpy(st->table + st->table_used, tuples.data(), sizeof(ArPeers) * (size_t)n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return hip_fail(e, "ar_register_graph_buffers: hipMemcpy");
+  for (int i = 0; i < n; ++i) st->buffers[st->graph_unreg[i]] = st->table + st->table_used + i;
+  st->table_used += n;
+  st->graph_unreg.clear();
+  return VLLM_AMD_OK;
+}
+
+// 1 in *timed_out if any barrier of this rank gave up waiting since init.  Reads the pinned host word:
+// no synchronisation (a time-out of a launch still in flight shows up once that launch has run).
 extern "C" int vllm_amd_ar_error(void* handle, int* timed_out) {
   VA_REQUIRE(handle && timed_out, VLLM_AMD_EINVAL, "ar_error: null pointer");
   ArState* st = (ArState*)handle;
-  uint32_t v = 0;
-  hipError_t e = hipMemcpy(&v, &((ArSignal*)st->sg.p[st->rank])->timed_out, sizeof(v), hipMemcpyDeviceToHost);
-  if (e != hipSuccess) return hip_fail(e, "ar_error: hipMemcpy");
-  *timed_out = (int)v;
+  *timed_out = (int)*(volatile uint32_t*)st->host_err;
   return VLLM_AMD_OK;
 }
 
 extern "C" int vllm_amd_ar_dispose(void* handle) {
-  delete (ArState*)handle;
+  ArState* st = (ArState*)handle;
+  if (st) {
+    for (auto& kv : st->opened) (void)hipIpcCloseMemHandle(kv.second);
+    if (st->host_err) (void)hipHostFree(st->host_err);
+  }
+  delete st;
   return VLLM_AMD_OK;
 }
 

@@ -44,6 +44,7 @@ void set_pa_variant(int v);
 void set_pa_sp(int v);
 void set_pa_group(int v);
 void set_pa_balance(int v);
+int get_pa_balance();
 void set_pa_order(int v);
 bool pa_order_enabled();
 // Split-K merge of partitions (v2 / rocm).

@@ -580,3 +580,13 @@ extern "C" int vllm_amd_set_tuning(const char* key, int value) {
   if (strcmp(key, "uni_decode") == 0) { g_uni_decode = value; return VLLM_AMD_OK; }
   VA_REQUIRE(false, VLLM_AMD_EINVAL, "set_tuning: unknown key %s", key);
 }
+
+// The current value of a tuning key (the torch shim asks for "pa_balance": it only registers the
+// workspace from paged_attention_v1 when the balanced form is on).
+extern "C" int vllm_amd_get_tuning(const char* key, int* value) {
+  VA_REQUIRE(key != nullptr && value != nullptr, VLLM_AMD_EINVAL, "get_tuning: null pointer");
+  if (strcmp(key, "pa_balance") == 0) { *value = get_pa_balance(); return VLLM_AMD_OK; }
+  if (strcmp(key, "mm_kernel") == 0) { *value = g_mm_kernel; return VLLM_AMD_OK; }
+  if (strcmp(key, "mm_splitk") == 0) { *value = g_mm_splitk; return VLLM_AMD_OK; }
+  VA_REQUIRE(false, VLLM_AMD_EINVAL, "get_tuning: unknown key %s", key);
+}

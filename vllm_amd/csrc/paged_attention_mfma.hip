@@ -741,6 +741,7 @@ void set_pa_order(int v) { g_pa_order = v; }
 bool pa_order_enabled() { return g_pa_order != 0; }
 static int g_pa_balance = 0;   // tuning "pa_balance": 1 = balanced v1 launches whenever possible, else never
 void set_pa_balance(int v) { g_pa_balance = v; }
+int get_pa_balance() { return g_pa_balance; }
 
 template <typename scalar_t, bool FP8, int HS, int BS, int VARIANT, bool PAD>
 static int launch_mfma_v(const PagedAttnParams& p) {

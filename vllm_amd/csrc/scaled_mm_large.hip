@@ -753,15 +753,18 @@ static int static_workspace(hipStream_t st, size_t bytes, int tiles, float** ws,
       void* p = nullptr;
       e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_mm_scratch));
       if (e != hipSuccess || !p) return hip_fail(e, "scaled_mm_static: hipGetSymbolAddress");
+      // Tickets start at zero ONCE per device (a __device__ array is zero when the code object loads; this
+      // memset only matters if an earlier process state left them otherwise).  Every split launch leaves its
+      // tickets at zero again (the last arriver resets them, kernel above), so no per-call memset -- it cost
+      // about what split-K saves on the shapes that split.
+      e = hipMemsetAsync((unsigned char*)p + STATIC_PART_BYTES, 0, STATIC_CTR_TILES * sizeof(unsigned), st);
+      if (e != hipSuccess) return hip_fail(e, "scaled_mm_static: hipMemsetAsync");
       g_mm_scratch_ptr[dev] = (unsigned char*)p;
     }
     base = g_mm_scratch_ptr[dev];
   }
   *ws = (float*)base;
   *ctr = (unsigned*)(base + STATIC_PART_BYTES);
-  // the array keeps the last call's contents: the tickets of this launch start at zero
-  e = hipMemsetAsync(*ctr, 0, (size_t)tiles * sizeof(unsigned), st);
-  if (e != hipSuccess) return hip_fail(e, "scaled_mm_static: hipMemsetAsync");
   return VLLM_AMD_OK;
 }
 

@@ -18,6 +18,7 @@
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -71,18 +72,21 @@ inline void* vptr(const OptTensor& t) { return t.has_value() ? t->data_ptr() : n
 // ---- the library workspace (vllm_amd_set_workspace) --------------------------------------
 // The C ABI allocates nothing, so this layer owns one buffer per device (4 stream slots x 16 MiB
 // + ticket counters) and registers it once, outside stream capture, before that device's first
-// scaled_mm / paged_attention_v1.  Without it the GEMM never splits over K and the balanced
-// paged_attention_v1 form is not taken.
+// scaled_mm -- and before its first paged_attention_v1 only when the balanced form ("pa_balance" = 1,
+// off by default) is on: nothing else of that op uses it.  Without it the GEMM never splits over K.
+// One host synchronisation, in that first call.  Launches under stream capture never take a workspace
+// slot, so a captured GEMM runs unsplit: split-K (M <= 64, K >= 12288: 17.2 -> 15.2 us) is an
+// eager-launch optimisation; bench.py's graph-timed GEMM legs time the unsplit form.
 constexpr int64_t kWsBytes = (64ll << 20) + (512ll << 10);
 std::mutex g_ws_mu;
 Tensor g_ws[64];
-bool g_ws_set[64];
+std::atomic<bool> g_ws_set[64];
 
 void ensure_workspace(const Tensor& t) {
   const int idx = t.get_device();
-  if (idx < 0 || idx >= 64 || g_ws_set[idx]) return;
+  if (idx < 0 || idx >= 64 || g_ws_set[idx].load(std::memory_order_acquire)) return;
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  if (g_ws_set[idx]) return;
+  if (g_ws_set[idx].load(std::memory_order_relaxed)) return;
   hipStream_t s = c10::hip::getCurrentHIPStream(idx).stream();
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
@@ -94,7 +98,7 @@ void ensure_workspace(const Tensor& t) {
   check(vllm_amd_set_workspace(g_ws[idx].data_ptr(), kWsBytes, (void*)s));
   // every stream's first launch must see the zeroed counters
   TORCH_CHECK(hipStreamSynchronize(s) == hipSuccess, "hipStreamSynchronize failed");
-  g_ws_set[idx] = true;
+  g_ws_set[idx].store(true, std::memory_order_release);
 }
 
 // ---- attention ---------------------------------------------------------------------------
@@ -108,7 +112,10 @@ void paged_attention_v1(Tensor& out, const Tensor& query, const Tensor& key_cach
   TORCH_CHECK(query.dim() == 3 && out.is_contiguous(), "out.is_contiguous() && query.dim() == 3");
   TORCH_CHECK(block_tables.scalar_type() == at::kInt && seq_lens.scalar_type() == at::kInt,
               "block_tables / seq_lens must be int32");
-  ensure_workspace(query);
+  {
+    int bal = 0;   // only the balanced form (opt-in) uses the workspace
+    if (vllm_amd_get_tuning("pa_balance", &bal) == VLLM_AMD_OK && bal == 1) ensure_workspace(query);
+  }
   DevGuard g(query.device());
   check(vllm_amd_paged_attention_v1(
       out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), (int)query.size(0),

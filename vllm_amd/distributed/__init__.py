@@ -137,28 +137,48 @@ def bench_row_parallel(device, dist, M: int = 256, hidden: int = 8192, iters: in
 
 def bench_custom_all_reduce(device, dist, M: int = 256, hidden: int = 8192, iters: int = 20):
     """The peer-to-peer all-reduce on the configs[3] message ([256, 8192] bf16 = 4 MiB) and on a
-    decode-sized one ([16, 8192] = 256 KiB) next to RCCL, across the ranks of `dist` -- only run
-    when VLLM_AMD_BENCH_CUSTOM_AR=1 (bench.py): this path has never run across GPUs.  The IPC
-    handles travel through a gloo group created here.  Results are checked against RCCL's."""
+    decode-sized one ([16, 8192] = 256 KiB) next to RCCL, across the ranks of `dist` (bench.py --gpus N;
+    VLLM_AMD_BENCH_CUSTOM_AR=0 skips it).  This path has never run across GPUs, so every step is guarded:
+    a 2 s barrier time limit, the result is checked against RCCL's BEFORE anything is timed, and the leg
+    stops at the first time-out or mismatch (all ranks agree on that through an RCCL reduction).  The IPC
+    handles travel through a gloo group created here."""
     import time
     from .custom_all_reduce import CustomAllreduce
+    world = dist.get_world_size()
     cpu_group = dist.new_group(backend="gloo")
     ar = CustomAllreduce(cpu_group, device)
     res = {"disabled": ar.disabled}
     if ar.disabled:
         return res
+
+    def any_rank(flag: bool) -> bool:
+        t = torch.tensor([1.0 if flag else 0.0], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item() > 0)
+
     try:
+        ar.set_timeout_ms(2000)
         for rows in (16, M):
             x = torch.randn((rows, hidden), device=device, dtype=torch.bfloat16)
             want = x.clone()
             dist.all_reduce(want)
-            got = ar.custom_all_reduce(x)
-            torch.cuda.synchronize()
-            if ar.timed_out():
-                res["timed_out"] = True     # a barrier gave up: stop here
+            failed, got = False, None
+            try:
+                got = ar.custom_all_reduce(x)
+                torch.cuda.synchronize()
+            except RuntimeError as e:
+                failed, res["error"] = True, str(e)[:200]
+            if any_rank(failed or ar.timed_out()):
+                res["timed_out"] = True     # a barrier gave up somewhere: stop here, nothing is timed
                 return res
-            res[f"rows{rows}_max_abs_diff_vs_rccl"] = float((got.float() - want.float()).abs().max())
-            for tag, fn in (("custom_us", lambda: ar.custom_all_reduce(x)), ("rccl_us", lambda: dist.all_reduce(x))):
+            diff = float((got.float() - want.float()).abs().max())
+            res[f"rows{rows}_max_abs_diff_vs_rccl"] = diff
+            # both sum `world` bf16 values in fp32 and round once; the orders differ: a few bf16 ulp of the sum
+            if any_rank(not (diff <= 0.05 * world)):
+                res["mismatch"] = True
+                return res
+            nbytes = x.numel() * 2
+            for tag, fn in (("custom", lambda: ar.custom_all_reduce(x)), ("rccl", lambda: dist.all_reduce(x))):
                 for _ in range(3):
                     fn()
                 torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
@@ -168,8 +188,12 @@ def bench_custom_all_reduce(device, dist, M: int = 256, hidden: int = 8192, iter
                 torch.cuda.synchronize()
                 t = torch.tensor([(time.perf_counter() - t0) / iters], device=device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                res[f"rows{rows}_{tag}"] = round(t.item() * 1e6, 2)
-        res["timed_out"] = ar.timed_out()
+                res[f"rows{rows}_{tag}_us"] = round(t.item() * 1e6, 2)
+                res[f"rows{rows}_{tag}_bus_gbps"] = round(2 * (world - 1) / world * nbytes / t.item() / 1e9, 1)
+                if any_rank(ar.timed_out()):
+                    res["timed_out"] = True
+                    return res
+        res["timed_out"] = False
     finally:
         ar.close()
     return res

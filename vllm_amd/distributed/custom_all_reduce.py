@@ -6,15 +6,21 @@ constructor arguments, `should_custom_ar`, `all_reduce`, `custom_all_reduce`, `c
 process group exactly as in the reference (`dist.all_gather_object`, so the group must not be
 NCCL).
 
-Differences: no graph-buffer registration -- under stream capture the input is copied into the
-pre-registered buffer like in eager mode (the copy is captured with the kernel); the P2P
-capability probe (`gpu_p2p_access_check`) is `torch.cuda.can_device_access_peer`.
+HIP graphs as in the reference (:175-215, 253-285): inside `with ar.capture():` an input met under
+stream capture is used in place (no copy); the pointer tuples the captured kernels read are filled by
+`register_graph_buffers()` when the context ends (IPC handles through the CPU group).  Outside a
+capture the input is copied into the pre-registered buffer.  The P2P capability probe
+(`gpu_p2p_access_check`) is `torch.cuda.can_device_access_peer`.
+
+A peer that does not arrive within the time limit (30 s; `set_timeout_ms`) never hangs the GPU: the
+launch's output is NaN and every later call of this object raises.
 
 STATUS: exercised with simulated ranks on one GPU and with two processes on one GPU; never across
 GPUs.  `tensor_model_parallel_all_reduce` only uses it when a `CustomAllreduce` is passed in."""
 from __future__ import annotations
 
 import ctypes as C
+from contextlib import contextmanager
 from typing import Optional, Union
 
 import torch
@@ -72,15 +78,54 @@ class CustomAllreduce:
         with torch.cuda.device(device):
             self.meta_ptrs = self.create_shared_buffer(meta_size() + max_size, group=group, uncached=True)
             self.buffer_ptrs = self.create_shared_buffer(max_size, group=group)
+            # tuples of input pointers the kernels read: 64 bytes per registered / graph-captured input
+            # (the reference allocates the same 8 MiB, custom_all_reduce.py:168-176)
+            self.rank_data = torch.empty(8 * 1024 * 1024, dtype=torch.uint8, device=self.device)
             self.max_size = max_size
             self.rank = rank
             self.world_size = world_size
             self.fully_connected = fully_connected
             h = C.c_void_p()
-            check(lib.vllm_amd_ar_init(C.byref(h), _ptr_array(self.meta_ptrs), world_size, rank,
+            check(lib.vllm_amd_ar_init(C.byref(h), _ptr_array(self.meta_ptrs), max_size,
+                                       self.rank_data.data_ptr(), self.rank_data.numel(), world_size, rank,
                                        int(fully_connected)))
             self._ptr = h
             check(lib.vllm_amd_ar_register_buffer(self._ptr, _ptr_array(self.buffer_ptrs)))
+
+    def set_timeout_ms(self, ms: int) -> None:
+        check(lib.vllm_amd_ar_set_timeout_ms(self._ptr, int(ms)))
+
+    @contextmanager
+    def capture(self):
+        """Wrap HIP-graph captures: the addresses used under capture are registered on every rank when
+        the context ends (custom_all_reduce.py:175-190)."""
+        try:
+            self._IS_CAPTURING = True
+            yield
+        finally:
+            self._IS_CAPTURING = False
+            if not self.disabled:
+                self.register_graph_buffers()
+
+    def register_graph_buffers(self) -> None:
+        import torch.distributed as dist
+        n = C.c_int(0)
+        check(lib.vllm_amd_ar_get_graph_buffer_ipc_meta(self._ptr, None, None, 0, C.byref(n)))
+        cap = n.value
+        handles = (C.c_ubyte * (_HANDLE_BYTES * max(cap, 1)))()
+        offsets = (C.c_int64 * max(cap, 1))()
+        if cap:
+            check(lib.vllm_amd_ar_get_graph_buffer_ipc_meta(self._ptr, handles, offsets, cap, C.byref(n)))
+        mine = [bytes(handles)[:_HANDLE_BYTES * cap], list(offsets)[:cap]]
+        world = dist.get_world_size(group=self.group)
+        all_data = [None] * world
+        dist.all_gather_object(all_data, mine, group=self.group)
+        assert all(len(d[1]) == cap for d in all_data), "ranks captured different numbers of all-reduce inputs"
+        if cap == 0:
+            return
+        hb = b"".join(d[0] for d in all_data)
+        ob = (C.c_int64 * (world * cap))(*[o for d in all_data for o in d[1]])
+        check(lib.vllm_amd_ar_register_graph_buffers(self._ptr, (C.c_ubyte * len(hb)).from_buffer_copy(hb), ob, cap))
 
     def should_custom_ar(self, inp: torch.Tensor) -> bool:
         if self.disabled:
@@ -107,12 +152,20 @@ class CustomAllreduce:
         return out
 
     def custom_all_reduce(self, input: torch.Tensor) -> Optional[torch.Tensor]:
+        """custom_all_reduce.py:253-285: under a graph capture inside `capture()` the input is used in place
+        (registered when the context ends); during the warm-up runs of that context only the output is
+        allocated; otherwise the input goes through the pre-registered buffer."""
         if self.disabled or not self.should_custom_ar(input):
             return None
+        if self._IS_CAPTURING:
+            if torch.cuda.is_current_stream_capturing():
+                return self.all_reduce(input, registered=True)
+            return torch.empty_like(input)      # warm-up: mimic the allocation pattern
         return self.all_reduce(input, registered=False)
 
     def timed_out(self) -> bool:
-        """True if a barrier of this rank ever gave up waiting for a peer (synchronises)."""
+        """True if a barrier of this rank ever gave up waiting for a peer (reads a pinned host word: no
+        synchronisation; every all_reduce after a time-out raises by itself)."""
         v = C.c_int(0)
         check(lib.vllm_amd_ar_error(self._ptr, C.byref(v)))
         return bool(v.value)

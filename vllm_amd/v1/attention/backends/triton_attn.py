@@ -166,6 +166,13 @@ class TritonAttentionImpl:
         # envs.VLLM_V1_USE_PREFILL_DECODE_ATTENTION (vllm/envs.py)
         self.force_prefill_decode_attn = os.environ.get(
             "VLLM_V1_USE_PREFILL_DECODE_ATTENTION", "0").lower() in ("1", "true")
+        # chunked_prefill_paged_decode (context_attention_fwd + paged_attention_rocm) stops at head size 128;
+        # the wider heads only exist in unified_attention (functional coverage, a plain VALU kernel)
+        if self.force_prefill_decode_attn and head_size > 128:
+            raise ValueError(
+                f"Head size {head_size} is not supported by TritonAttentionBackend with "
+                "VLLM_V1_USE_PREFILL_DECODE_ATTENTION=1. Supported head sizes there are: "
+                f"{[h for h in TritonAttentionBackend.get_supported_head_sizes() if h <= 128]}.")
 
     def forward(self, layer: torch.nn.Module, query: torch.Tensor, key: torch.Tensor,
                 value: torch.Tensor, kv_cache: torch.Tensor, attn_metadata,
