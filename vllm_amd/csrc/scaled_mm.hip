@@ -343,7 +343,7 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
       }
       sel = 2;
     }
-    if (sel == 0 || sel == 11 || sel > 17) {
+    if (sel == 0 || sel == 11 || sel > 28) {
       // Largest tile that still yields ~3/4 of a full wave of workgroups (256 CUs); rows of
       // a tile beyond M are wasted MFMA work, so BM <= 2 M.  With more than one wave of tiles the
       // variant that fits several workgroups per CU wins, below that the variant that takes
@@ -363,7 +363,10 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
           // (more than one round of tiles: the variant that fits two workgroups per CU -- 4096 x 6144
           // at M 768 = 288 tiles of 128 x 128: 38.6 -> 30.2 us, at M 384 = 288 tiles of 128 x 64: 24.4 ->
           // 20.6 us)
-          sel = (nt > 256 || K % (128 * t.kb) != 0 || (i == 3 && K >= 8192)) ? t.id : t.id_kb;
+          // (round 3, weights streamed from HBM as in a model -- bench.py rotates them now,
+          // profiles/r03_gemm_sweep_rotating.csv: the 64 x 64 tile with one K block per barrier wins at
+          // every K: 4096 x 4096 at M 256 12.7 vs 15.2 us, 4096 x 6144 at M 128 13.4 vs 15.9 us)
+          sel = (nt > 256 || K % (128 * t.kb) != 0 || i == 3) ? t.id : t.id_kb;
           // Even the smallest tile leaves half the CUs idle and the K loop is long: two K
           // slices (in-kernel fix-up, scaled_mm_large.hip).  The fix-up is a chain of three
           // device-scope round trips (~2.5 us), so it pays only here: 14336x4096, M 16..64:

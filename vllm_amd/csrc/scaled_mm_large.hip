@@ -820,6 +820,9 @@ static int launch_glds_shape(int shape, const GldsArgs& g) {
     case 15: return launch_glds_t<out_t, 256, 256, 2, 4, 5, 1, false>(g);   // ring of five half stages
     case 16: return launch_glds_t<out_t, 256, 256, 2, 4, 2, 1, false, 1>(g);   // waves 4-7 stage everything
     case 17: return launch_glds_t<out_t, 256, 256, 4, 4, 2, 1, false>(g);      // 16 waves, 64 x 64 each
+    case 26: return launch_glds_t<out_t, 64, 64, 2, 2, 8, 1, true>(g);         // deeper rings: weights from HBM
+    case 27: return launch_glds_t<out_t, 64, 64, 2, 2, 4, 2, true>(g);
+    case 28: return launch_glds_t<out_t, 128, 64, 4, 2, 6, 1, true>(g);
     default: return launch_glds_t<out_t, 32, 128, 1, 4, 3, 2, true>(g);   // 13
   }
 }
@@ -838,8 +841,8 @@ int launch_scaled_mm_large(int shape, void* out, const void* a, const void* b,
                            int out_dtype, bool vec, int splits, int ws_mode, hipStream_t st) {
   // shape = a GldsTile::id of the table in scaled_mm.hip.  Shapes that consume KB blocks per
   // barrier need K % (128 KB) == 0; otherwise the same tile with KB = 1.
-  static const int kb_of[18] = {1, 1, 1, 1, 2, 1, 2, 1, 4, 1, 4, 1, 1, 2, 1, 1, 1, 1};
-  if (shape < 2 || shape > 17 || shape == 11) shape = 3;
+  static const int kb_of[29] = {1, 1, 1, 1, 2, 1, 2, 1, 4, 1, 4, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1};
+  if (shape < 2 || shape > 28 || (shape > 17 && shape < 26) || shape == 11) shape = 3;
   if (K % (LBK * kb_of[shape]) != 0) shape -= 1;
   const GldsArgs g{out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc, asn, bsn, vec, st,
                    splits, ws_mode};
