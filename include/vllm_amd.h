@@ -472,7 +472,15 @@ int vllm_amd_ar_free_shared(void* ptr);
 /*                 14 = 256x256 tile on 4 waves (accumulators in AGPRs),        */
 /*                 15 = ring of five half stages, 16 = waves 4-7 stage the    */
 /*                 whole tile (14-16: 256x256 variants, measured, not           */
-/*                 used by the heuristic: profiles/r02_gemm_ablation.txt)       */
+/*                 used by the heuristic: profiles/r02_gemm_ablation.txt),      */
+/*                 17 = 256x256 on 16 waves; 18..25 = scaled_mm_pp.hip (value - 18:   */
+/*                 bit 0 stagger, bit 1 persistent, bit 2 stagger by a quarter     */
+/*                 block; 21 = what the heuristic ships for MFMA-bound shapes),     */
+/*                 26..28 = 64x64 / 128x64 tiles with deeper rings (no gain)        */
+/*   "mm_patch":   tile columns per super-column of the scaled_mm_pp tile order    */
+/*                 (default 8; <= 1 = column-major)                                  */
+/*   "mm_store":   scaled_mm_pp measurement: 3 = no output stores (garbage)         */
+/*   "mm_prio":    scaled_mm_pp measurement: 1 / 2 = s_setprio 1 for waves 4-7 / 0-3 */
 /*   "pf_rows":    query rows per workgroup of the prefill kernels (0 = default,    */
 /*                 64 / 128); 1 = unified_attention without GQA packing          */
 /*   "uni_decode": 0 = unified_attention never uses its decode kernel (1 =     */

@@ -174,7 +174,7 @@ def force_kernel():
     _lib.set_tuning("mm_splitk", 0)
 
 
-@pytest.mark.parametrize("kernel", list(range(1, 26)))
+@pytest.mark.parametrize("kernel", list(range(1, 29)))
 @pytest.mark.parametrize("MNK", [(300, 520, 256), (256, 256, 1024), (257, 971, 384), (640, 1288, 2048),
                                  (40, 8, 128 * 3), (5, 264, 512), (32, 1040, 1024)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
@@ -187,7 +187,7 @@ def test_scaled_mm_every_tile_kernel(ops, oracle, force_kernel, kernel, MNK, out
     check(ops, oracle, M, N, K, False, False, out_dtype, bias=False, seed=M + N + kernel)
 
 
-@pytest.mark.parametrize("kernel", list(range(1, 11)) + list(range(12, 26)))
+@pytest.mark.parametrize("kernel", list(range(1, 11)) + list(range(12, 29)))
 def test_scaled_mm_integer_exact_every_kernel(ops, force_kernel, kernel):
     M, N, K = 512, 768, 640
     g = torch.Generator().manual_seed(kernel)
@@ -239,7 +239,7 @@ def test_scaled_mm_several_tiles_per_workgroup(ops, MN, per_channel):
     assert torch.equal(out, ref)
 
 
-SPLIT_KERNELS = [3, 4, 5, 6, 7, 8, 9, 10, 12, 13]
+SPLIT_KERNELS = [3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 26, 27, 28]
 
 
 @pytest.mark.parametrize("kernel", SPLIT_KERNELS)
