@@ -322,7 +322,10 @@ def run_cache_quant(device, iters=20):
     # decode-step cache write at configs[1]: T=64 tokens ... plus a prefill-sized one
     # (prefill: 4 sequences of T/4 consecutive slots over scattered blocks, starting 5 slots
     # into a block as after a chunk boundary; "scattered": every token in a different block)
+    # ("prefill_aligned": sequences that start on a block boundary -- a fresh prefill; "prefill": 5 slots into
+    # a block, as after a chunk boundary)
     for name, T in (("decode_T64", 64), ("prefill_T8192", 8192), ("prefill_T32768", 32768),
+                    ("prefill_aligned_T8192", 8192), ("prefill_aligned_T32768", 32768),
                     ("scattered_T8192", 8192)):
         KVH, D, BS = 8, 128, 16
         NB = max(T // BS * 2, 64)
@@ -332,7 +335,7 @@ def run_cache_quant(device, iters=20):
         vc = torch.zeros((NB, KVH, D, BS), dtype=torch.uint8, device=device)
         if name.startswith("prefill"):
             t = torch.arange(T, device=device)
-            seq, pos = t // (T // 4), t % (T // 4) + 5
+            seq, pos = t // (T // 4), t % (T // 4) + (0 if "aligned" in name else 5)
             per_seq = (T // 4 + 5 + BS - 1) // BS
             perm = torch.randperm(NB, device=device)
             slots = (perm[seq * per_seq + pos // BS] * BS + pos % BS).to(torch.int64)

@@ -202,6 +202,43 @@ __global__ __launch_bounds__(256) void reshape_and_cache_runs_kernel(
 
   // rows of the transposed tile: column q = (slot0 % 16) + token keeps the slots' alignment,
   // so columns [0,16) (segment A) and [16,32) (segment B) are 16-slot groups inside a block
+  if constexpr (CS == 1) {
+    // fp8, whole 16-slot groups (round 3): a thread takes FOUR consecutive d -- one 4-byte LDS read per token
+    // instead of four single-byte ones (the byte reads made this kernel LDS-issue bound: 16 ds_read_u8 per
+    // 16-byte row) -- transposes the 4 x 16 bytes in registers (v_perm_b32) and stores four 16-byte rows.
+    // Partial groups (the two ends of a run that starts mid-block) keep the per-row path below: the same
+    // scheme with 4-byte and single-byte stores measured slower there (32768 tokens 50.6 -> 79.5 us).
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int q0 = 16 * hh;
+      const int lo = colbase - q0 > 0 ? colbase - q0 : 0;
+      const int hi = colbase + n - q0 < 16 ? colbase + n - q0 : 16;
+      if (!(lo == 0 && hi == 16)) continue;   // uniform
+      const int64_t sbase = hh == 0 ? slot0 - colbase : slotB;
+      int64_t blk, off;
+      split(sbase, blk, off);
+      for (int dg = tid; dg < width / 4; dg += 256) {
+        uint32_t col[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+          col[p] = *reinterpret_cast<const uint32_t*>(&vt[q0 + p - colbase][dg * 4]);
+        cache_t* dst = value_cache + blk * blk_elems + head_off + (int64_t)(dg * 4) * block_size + off;
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t sel = 0x0c0c0000u | ((4u + e) << 8) | (uint32_t)e;   // byte e of (S1, S0)
+          u32x4 row;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t t0 = __builtin_amdgcn_perm(col[4 * k + 1], col[4 * k], sel);
+            const uint32_t t1 = __builtin_amdgcn_perm(col[4 * k + 3], col[4 * k + 2], sel);
+            row[k] = __builtin_amdgcn_perm(t1, t0, 0x05040100u);
+          }
+          *reinterpret_cast<u32x4*>(dst + (int64_t)e * block_size) = row;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int u = 0; u < RI; ++u) {
     const int d = tid + 256 * u;   // (head, d) row: rows of consecutive heads are contiguous
@@ -212,6 +249,7 @@ __global__ __launch_bounds__(256) void reshape_and_cache_runs_kernel(
       const int lo = colbase - q0 > 0 ? colbase - q0 : 0;
       const int hi = colbase + n - q0 < 16 ? colbase + n - q0 : 16;
       if (hi <= lo) continue;   // uniform
+      if (CS == 1 && lo == 0 && hi == 16) continue;   // done above
       const int64_t sbase = hh == 0 ? slot0 - colbase : slotB;   // first slot of the 16-slot group
       int64_t blk, off;
       split(sbase, blk, off);
@@ -362,7 +400,7 @@ __global__ void copy_blocks_kernel(uint8_t* __restrict__ kc, uint8_t* __restrict
 
 using namespace va;
 
-namespace va { int g_cache_runs = 1; }   // tuning "cache_runs": 0 = always the per-token kernel
+namespace va { int g_cache_runs = 1; int g_cache_hpw = 0; }   // "cache_hpw": heads per workgroup of the runs kernel (0 = heuristic)   // tuning "cache_runs": 0 = always the per-token kernel
 
 static inline bool aligned(const void* p, size_t a) { return (((uintptr_t)p) & (a - 1)) == 0; }
 
@@ -387,7 +425,10 @@ static int launch_reshape_and_cache(const void* key, const void* value, void* kc
     int hpw = 512 / head_size;   // heads per workgroup: hpw * head_size <= 512 elements
     if (hpw > num_heads) hpw = num_heads;
     // fewer heads per workgroup while the launch would not fill the chip a few times over
-    while (hpw > 1 && (int64_t)((num_tokens + 15) / 16) * ((num_heads + hpw - 1) / hpw) < 4096) hpw /= 2;
+    // (round 3, with the 4-byte V path: 8192 tokens 19.8 us with 1 head per workgroup, 14.3 with 4; 2048 tokens 6.8 / 6.2
+    // with 1 / 2: tools/bench_cache_hpw.py)
+    while (hpw > 1 && (int64_t)((num_tokens + 15) / 16) * ((num_heads + hpw - 1) / hpw) < 512) hpw /= 2;
+    if (g_cache_hpw > 0 && g_cache_hpw * head_size <= 512 && g_cache_hpw <= num_heads) hpw = g_cache_hpw;
     hipLaunchKernelGGL((reshape_and_cache_runs_kernel<scalar_t, cache_t, FP8>),
                        dim3((num_tokens + 15) / 16, (num_heads + hpw - 1) / hpw), dim3(256), 0, st,
                        (const scalar_t*)key, (const scalar_t*)value, (cache_t*)kc, (cache_t*)vc,
