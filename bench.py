@@ -606,6 +606,36 @@ def launch_ranks(n):
     return rc
 
 
+def run_custom_ar_children(rank, local_rank, world, timeout_s=150):
+    """One child per rank (started by the rank itself); rank 0 relays its child's JSON."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world),
+               MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "GROUP_RANK", "ROLE_RANK"):
+        env.pop(k, None)
+    try:
+        p = subprocess.Popen([sys.executable, "-m", "vllm_amd.distributed.ar_bench"], env=env, cwd=ROOT,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            out, err = p.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, err = p.communicate()
+            return {"error": f"child timed out after {timeout_s} s"}
+        if rank != 0:
+            return None
+        for ln in reversed(out.strip().splitlines()):
+            if ln.startswith("{"):
+                res = json.loads(ln)
+                res["child_rc"] = p.returncode
+                return res
+        return {"error": f"child rc {p.returncode}: {err.strip()[-300:]}"}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def dry_run(args):
     """CPU rehearsal of the N-rank launch path (tests): rendezvous, one all-reduce, rank 0 prints."""
     import torch.distributed as dist
@@ -786,13 +816,10 @@ def main():
         if rank == 0:
             line.setdefault("extra", {})["row_parallel_tp"] = rp
         if world > 1 and os.environ.get("VLLM_AMD_BENCH_CUSTOM_AR", "1") != "0":
-            # the peer-to-peer all-reduce beside RCCL: result-checked first, 2 s barrier limit, the leg stops
-            # at the first time-out or mismatch (it has only run with simulated ranks on one GPU so far)
-            from vllm_amd.distributed import bench_custom_all_reduce
-            try:
-                ca = bench_custom_all_reduce(device, dist)
-            except Exception as e:
-                ca = {"error": f"{type(e).__name__}: {e}"}
+            # the peer-to-peer all-reduce beside RCCL (result-checked first, 2 s barrier limit).  It has only run
+            # with simulated ranks on one GPU so far, so every rank runs it in a CHILD process with process groups
+            # of its own (vllm_amd/distributed/ar_bench.py): whatever happens there, this process prints its line.
+            ca = run_custom_ar_children(rank, local_rank, world)
             if rank == 0:
                 line.setdefault("extra", {})["custom_all_reduce"] = ca
         dist.barrier()

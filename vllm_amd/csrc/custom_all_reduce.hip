@@ -141,6 +141,12 @@ __global__ __launch_bounds__(AR_THREADS) void ar_one_stage_kernel(const ArPeers*
   __syncthreads();
   const ArPeers bufs = *bufs_p;
   const uint32_t flag = self->epoch[blockIdx.x] + 1;
+  if (ld_sys(ctl.host_err) != 0) {   // an earlier launch of this handle gave up: no further waiting (launches
+    // already enqueued behind it would each sit out the time limit twice), the output says so
+    for (int64_t i = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * AR_THREADS)
+      out[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    return;
+  }
   // every peer's input is complete (its earlier kernels released it at their end) -- and nothing this
   // GPU may still cache of those buffers from the previous launch is served again (acquire)
   ar_barrier<NG, 0, false, true>(sg, self, rank, flag, ctl, &bad);
@@ -163,6 +169,11 @@ __global__ __launch_bounds__(AR_THREADS) void ar_two_stage_kernel(const ArPeers*
   __syncthreads();
   const ArPeers bufs = *bufs_p;
   const uint32_t flag = self->epoch[blockIdx.x] + 1;
+  if (ld_sys(ctl.host_err) != 0) {   // see the one-stage kernel
+    for (int64_t i = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * AR_THREADS)
+      out[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    return;
+  }
   const int64_t part = nvec / NG;   // slice r = [r part, (r+1) part), the last one takes the rest
   auto slice_begin = [&](int r) { return (int64_t)r * part; };
   auto slice_end = [&](int r) { return r == NG - 1 ? nvec : (int64_t)(r + 1) * part; };

@@ -142,10 +142,20 @@ def bench_custom_all_reduce(device, dist, M: int = 256, hidden: int = 8192, iter
     a 2 s barrier time limit, the result is checked against RCCL's BEFORE anything is timed, and the leg
     stops at the first time-out or mismatch (all ranks agree on that through an RCCL reduction).  The IPC
     handles travel through a gloo group created here."""
+    import os
+    import sys
     import time
     from .custom_all_reduce import CustomAllreduce
     world = dist.get_world_size()
+    verbose = os.environ.get("VLLM_AMD_AR_BENCH_VERBOSE") == "1"
+
+    def say(msg):
+        if verbose:
+            print(f"[ar_bench rank {dist.get_rank()}] {msg}", file=sys.stderr, flush=True)
+
+    say("new gloo group")
     cpu_group = dist.new_group(backend="gloo")
+    say("CustomAllreduce")
     ar = CustomAllreduce(cpu_group, device)
     res = {"disabled": ar.disabled}
     if ar.disabled:
@@ -161,7 +171,10 @@ def bench_custom_all_reduce(device, dist, M: int = 256, hidden: int = 8192, iter
         for rows in (16, M):
             x = torch.randn((rows, hidden), device=device, dtype=torch.bfloat16)
             want = x.clone()
+            say(f"rows {rows}: reference all_reduce")
             dist.all_reduce(want)
+            torch.cuda.synchronize()
+            say("custom all_reduce")
             failed, got = False, None
             try:
                 got = ar.custom_all_reduce(x)
@@ -179,6 +192,7 @@ def bench_custom_all_reduce(device, dist, M: int = 256, hidden: int = 8192, iter
                 return res
             nbytes = x.numel() * 2
             for tag, fn in (("custom", lambda: ar.custom_all_reduce(x)), ("rccl", lambda: dist.all_reduce(x))):
+                say(f"timing {tag}")
                 for _ in range(3):
                     fn()
                 torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
