@@ -289,8 +289,14 @@ int vllm_amd_fused_add_rms_norm_static_fp8_quant(void* out, const void* input,
  * (csrc/quantization/fused_kernels/fused_layernorm_dynamic_per_token_quant.cu:11-155,
  * layernorm_utils.cuh:20-119; wrapper _custom_ops.py:368-384).  scale_ub and residual
  * may be NULL; scales is float[num_tokens] (out); residual is updated in place with
- * scalar_t(input + residual).  int8 output is outside this path (VLLM_AMD_EUNSUPPORTED
- * is raised by the Python layer). */
+ * scalar_t(input + residual).  The _int8 form is the same op with an int8 output
+ * (fused_layernorm_dynamic_per_token_quant.cu:33-36, quant_conversions.cuh:15-31, 51-61:
+ * scale = max(amax / 127, FLT_EPSILON), q = saturate(nearbyint(y * (1 / scale))); no scale_ub):
+ * functional coverage on the strided kernel, outside the fp8 path. */
+int vllm_amd_rms_norm_dynamic_per_token_quant_int8(void* out, const void* input, const void* weight,
+                                                   float* scales, float epsilon, void* residual,
+                                                   int64_t num_tokens, int hidden_size, int dtype,
+                                                   void* stream);
 int vllm_amd_rms_norm_dynamic_per_token_quant(void* out, const void* input,
                                               const void* weight, float* scales,
                                               float epsilon, const float* scale_ub,

@@ -110,11 +110,36 @@ def test_rms_norm_dynamic_per_token_quant(ops, oracle, shape, dtype, add_residua
     check_dynamic(q.cpu(), s.cpu(), q_ref, s_ref, dtype, H)
 
 
-def test_rms_norm_dynamic_rejects_int8(ops):
-    x = torch.randn(4, 64, device="cuda", dtype=torch.bfloat16)
-    with pytest.raises(RuntimeError, match="int8"):
-        ops.rms_norm_dynamic_per_token_quant(x, torch.ones(64, device="cuda", dtype=torch.bfloat16),
-                                             EPS, torch.int8)
+@pytest.mark.parametrize("shape", [(1, 64), (7, 1027), (83, 2048), (33, 5120), (5, 8200)])
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("add_residual", [False, True])
+def test_rms_norm_dynamic_per_token_quant_int8(ops, shape, dtype, add_residual):
+    """int8 output (fused_layernorm_dynamic_per_token_quant.cu:33-36): against the reference test's own
+    route (test_fused_quant_layernorm.py:40-74, 156-166): RMSNorm.forward_native, then the per-token int8
+    quant of tests/kernels/quant_utils.py:22-62 (scale = amax / 127, round(x * (1 / scale)), clamp), restated
+    in torch on the CPU.  Tolerance: the reference's atol = 1 on the codes; scales rtol 1e-5 up to one ulp of
+    the input dtype in the row maximum; the residual write-back is exact.  Parity unpinned beyond that (no
+    reference execution possible here)."""
+    T, H = shape
+    x, res, w = mk(T, H, dtype, T + H + 7)
+    xf = x.float() + (res.float() if add_residual else 0.0)
+    new_res = xf.to(dtype)
+    var = xf.pow(2).mean(dim=-1, keepdim=True)
+    y = ((xf * torch.rsqrt(var + EPS)).to(dtype) * w).float()
+    scales = (y.abs().amax(dim=-1, keepdim=True) / 127.0).clamp(min=torch.finfo(torch.float32).eps)
+    want = (y * (1.0 / scales)).round().clamp(-128, 127).to(torch.int8)
+    r = res.cuda().clone() if add_residual else None
+    q, s = ops.rms_norm_dynamic_per_token_quant(x.cuda(), w.cuda(), EPS, torch.int8, None, r)
+    assert q.dtype == torch.int8 and q.shape == x.shape
+    tol = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+    torch.testing.assert_close(s.cpu(), scales, rtol=tol, atol=0)
+    assert (q.cpu().int() - want.int()).abs().max().item() <= 1
+    assert (q.cpu() != want).float().mean().item() <= 0.02
+    if add_residual:
+        assert torch.equal(r.cpu(), new_res)
+    with pytest.raises(RuntimeError, match="scale_ub"):
+        ops.rms_norm_dynamic_per_token_quant(x.cuda(), w.cuda(), EPS, torch.int8,
+                                             torch.tensor([1.0], device="cuda"), None)
 
 
 @pytest.mark.parametrize("num_tokens", [1, 17, 86, 1234])

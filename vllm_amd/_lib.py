@@ -52,6 +52,7 @@ SIGNATURES = {
     "vllm_amd_rms_norm_static_fp8_quant": [_vp, _vp, _vp, _vp, _f, _i64, _i, _i64, _i, _vp],
     "vllm_amd_fused_add_rms_norm_static_fp8_quant": [
         _vp, _vp, _vp, _vp, _vp, _f, _i64, _i, _i64, _i, _vp],
+    "vllm_amd_rms_norm_dynamic_per_token_quant_int8": [_vp, _vp, _vp, _vp, _f, _vp, _i64, _i, _i, _vp],
     "vllm_amd_rms_norm_dynamic_per_token_quant": [
         _vp, _vp, _vp, _vp, _f, _vp, _vp, _i64, _i, _i, _vp],
     "vllm_amd_silu_and_mul_quant": [_vp, _vp, _vp, _i64, _i, _i, _vp],

@@ -55,7 +55,7 @@ __device__ __forceinline__ float norm_elem(float x, float rms, T w) {
 }
 __device__ __forceinline__ float clamp_q(float x) { return fmaxf(-kQMax, fminf(x, kQMax)); }
 
-enum { MODE_STATIC = 0, MODE_ADD_STATIC = 1, MODE_DYNAMIC = 2, MODE_QUANT = 3 };
+enum { MODE_STATIC = 0, MODE_ADD_STATIC = 1, MODE_DYNAMIC = 2, MODE_QUANT = 3, MODE_DYNAMIC_I8 = 4 };
 
 // x of one element under the three residual conventions; updates the residual
 template <typename T, int MODE>
@@ -213,17 +213,36 @@ __global__ __launch_bounds__(ROW_THREADS) void row_quant_generic_kernel(
   for (int i = threadIdx.x; i < hidden; i += ROW_THREADS) {
     float x;
     if constexpr (MODE == MODE_ADD_STATIC) x = take_x<T, MODE>(tin[i], &tres[i], true);
-    else x = to_f32(tin[i]) + ((MODE == MODE_DYNAMIC && has_res) ? to_f32(tres[i]) : 0.f);
+    else x = to_f32(tin[i]) + (((MODE == MODE_DYNAMIC || MODE == MODE_DYNAMIC_I8) && has_res) ? to_f32(tres[i]) : 0.f);
     ss += x * x;
   }
   ss = block_sum(ss, red);
   const float rms = rsqrtf(ss / (float)hidden + eps);
   auto xval = [&](int i) -> float {
     if constexpr (MODE == MODE_ADD_STATIC) return to_f32(tres[i]);
-    else return to_f32(tin[i]) + ((MODE == MODE_DYNAMIC && has_res) ? to_f32(tres[i]) : 0.f);
+    else return to_f32(tin[i]) + (((MODE == MODE_DYNAMIC || MODE == MODE_DYNAMIC_I8) && has_res) ? to_f32(tres[i]) : 0.f);
   };
   float s;
-  if constexpr (MODE == MODE_DYNAMIC) {
+  if constexpr (MODE == MODE_DYNAMIC_I8) {
+    // int8 output (fused_layernorm_dynamic_per_token_quant.cu:33-36, layernorm_utils.cuh:51-94,
+    // quant_conversions.cuh:15-31, 51-61): scale = max(amax / 127, FLT_EPSILON), no upper bound;
+    // q = saturate(nearbyint(y * (1 / scale)))
+    float amax = 0.f;
+    for (int i = threadIdx.x; i < hidden; i += ROW_THREADS)
+      amax = fmaxf(amax, fabsf(norm_elem<T>(xval(i), rms, weight[i])));
+    amax = block_max2(amax, red);
+    s = fmaxf(amax / 127.0f, 1.1920928955078125e-07f);
+    if (threadIdx.x == 0) scales[t] = s;
+    const float inv = 1.0f / s;
+    for (int i = threadIdx.x; i < hidden; i += ROW_THREADS) {
+      const float x = xval(i);
+      float q = nearbyintf(norm_elem<T>(x, rms, weight[i]) * inv);
+      q = q < -128.f ? -128.f : (q > 127.f ? 127.f : q);
+      out[t * hidden + i] = (uint8_t)(int8_t)q;
+      if (has_res) tres[i] = from_f32<T>(x);
+    }
+    return;
+  } else if constexpr (MODE == MODE_DYNAMIC) {
     float amax = 0.f;
     for (int i = threadIdx.x; i < hidden; i += ROW_THREADS)
       amax = fmaxf(amax, fabsf(norm_elem<T>(xval(i), rms, weight[i])));
@@ -358,8 +377,11 @@ static void launch_row(void* out, const void* in, int64_t in_stride, void* resid
                        const void* weight, const float* scale, float* scales,
                        const float* scale_ub, float eps, int64_t num_tokens, int hidden,
                        hipStream_t st) {
-  if (!launch_row_regs<T, MODE>(out, in, in_stride, residual, weight, scale, scales, scale_ub, eps,
-                                num_tokens, hidden, st))
+  bool done = false;
+  if constexpr (MODE != MODE_DYNAMIC_I8)   // int8 output: the strided kernel only (outside the fp8 path)
+    done = launch_row_regs<T, MODE>(out, in, in_stride, residual, weight, scale, scales, scale_ub, eps,
+                                    num_tokens, hidden, st);
+  if (!done)
     hipLaunchKernelGGL((row_quant_generic_kernel<T, MODE>), dim3((unsigned)num_tokens),
                        dim3(ROW_THREADS), 0, st, (uint8_t*)out, (const T*)in, in_stride,
                        (T*)residual, (const T*)weight, scale, scales, scale_ub, eps, hidden);
@@ -444,6 +466,19 @@ extern "C" int vllm_amd_rms_norm_dynamic_per_token_quant(void* out, const void* 
   return row_entry<MODE_DYNAMIC>("rms_norm_dynamic_per_token_quant", out, input, hidden_size,
                                  residual, weight, nullptr, scales, scale_ub, epsilon, num_tokens,
                                  hidden_size, dtype, (hipStream_t)stream);
+}
+
+// int8 output of the same op (scale_ub is fp8-only in the reference: TORCH_CHECK at :142-144)
+extern "C" int vllm_amd_rms_norm_dynamic_per_token_quant_int8(void* out, const void* input,
+                                                              const void* weight, float* scales,
+                                                              float epsilon, void* residual,
+                                                              int64_t num_tokens, int hidden_size,
+                                                              int dtype, void* stream) {
+  VA_REQUIRE(scales != nullptr || num_tokens == 0, VLLM_AMD_EINVAL,
+             "rms_norm_dynamic_per_token_quant: null scales");
+  return row_entry<MODE_DYNAMIC_I8>("rms_norm_dynamic_per_token_quant", out, input, hidden_size,
+                                    residual, weight, nullptr, scales, nullptr, epsilon, num_tokens,
+                                    hidden_size, dtype, (hipStream_t)stream);
 }
 
 extern "C" int vllm_amd_silu_and_mul_quant(void* out, const void* input, const float* scale,

@@ -363,18 +363,29 @@ void fused_add_rms_norm_static_fp8_quant(Tensor& result, const Tensor& input, Te
 void rms_norm_dynamic_per_token_quant(Tensor& result, const Tensor& input, const Tensor& weight, Tensor& scale,
                                       double epsilon, const OptTensor& scale_ub, OptTensor residual) {
   need_devs(result, input, weight, scale, scale_ub, residual);
-  TORCH_CHECK(result.scalar_type() != at::kChar,
-              "rms_norm_dynamic_per_token_quant: int8 output is outside the fp8 path this library implements");
-  fp8_out(result);
+  const bool i8 = result.scalar_type() == at::kChar;
+  if (i8) {
+    // fused_layernorm_dynamic_per_token_quant.cu:139-146: int8 or fp8 output, scale_ub only with fp8
+    TORCH_CHECK(!scale_ub.has_value(), "rms_norm_dynamic_per_token_quant: scale_ub needs an fp8 output");
+    TORCH_CHECK(result.is_contiguous(), "out.is_contiguous()");
+  } else {
+    fp8_out(result);
+  }
   TORCH_CHECK(input.is_contiguous(), "input.is_contiguous()");
   TORCH_CHECK(scale.scalar_type() == at::kFloat, "scales.dtype() == torch::kFloat32");
   TORCH_CHECK(!residual.has_value() || residual->is_contiguous(), "residual.is_contiguous()");
   const int64_t hidden = input.size(-1);
   DevGuard g(input.device());
-  check(vllm_amd_rms_norm_dynamic_per_token_quant(result.data_ptr(), input.data_ptr(), weight.data_ptr(),
-                                                  (float*)scale.data_ptr(), (float)epsilon, fptr(scale_ub),
-                                                  vptr(residual), rows_of(input, hidden), (int)hidden, dt(input),
-                                                  stream_of(input)));
+  if (i8)
+    check(vllm_amd_rms_norm_dynamic_per_token_quant_int8(result.data_ptr(), input.data_ptr(), weight.data_ptr(),
+                                                         (float*)scale.data_ptr(), (float)epsilon, vptr(residual),
+                                                         rows_of(input, hidden), (int)hidden, dt(input),
+                                                         stream_of(input)));
+  else
+    check(vllm_amd_rms_norm_dynamic_per_token_quant(result.data_ptr(), input.data_ptr(), weight.data_ptr(),
+                                                    (float*)scale.data_ptr(), (float)epsilon, fptr(scale_ub),
+                                                    vptr(residual), rows_of(input, hidden), (int)hidden, dt(input),
+                                                    stream_of(input)));
 }
 
 // csrc/quantization/activation_kernels.cu:112-121
