@@ -286,9 +286,17 @@ def run_scaled_mm(device, shapes, Ms, iters=20, rotate=True):
             flops = 2.0 * M * N * K
             nbytes = M * K + K * N + 2 * M * N + 4 * (M + N)
             bound = min(FP8_DENSE_PEAK_TFLOPS, HBM_PEAK_GBPS * 1e9 * (flops / nbytes) / 1e12)
-            res.append(dict(M=M, K=K, N=N, us=round(t * 1e6, 2), tflops=round(flops / t / 1e12, 2),
-                            gbps=round(nbytes / t / 1e9, 1), roof_tflops=round(bound, 1),
-                            frac=round(flops / t / 1e12 / bound, 4), weight_copies=copies))
+            row = dict(M=M, K=K, N=N, us=round(t * 1e6, 2), tflops=round(flops / t / 1e12, 2),
+                       gbps=round(nbytes / t / 1e9, 1), roof_tflops=round(bound, 1),
+                       frac=round(flops / t / 1e12 / bound, 4), weight_copies=copies)
+            if rotate and M >= 4096:
+                # the same launch with ONE weight buffer (Infinity-Cache resident, as rounds 1-2 timed it):
+                # what the kernel does when the weight stream costs nothing
+                wt0, ws0 = wqs[0]
+                t1 = time_gpu_graph(lambda: torch.ops._C.cutlass_scaled_mm(out, aq, wt0, as_, ws0, None), iters)
+                row["resident_weights_us"] = round(t1 * 1e6, 2)
+                row["resident_weights_tflops"] = round(flops / t1 / 1e12, 2)
+            res.append(row)
         del wqs
         torch.cuda.empty_cache()
     return res
