@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64 * NW) void scaled_mm_pp_kernel(
     for (int gb = 0; gb <= total; ++gb) {
       // own LDS-DMA of this block has landed; then everybody's has, and everybody is done reading the
       // other stage (group B: has ITS fragments of it in registers)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (prio != 9) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ("mm_prio" 9, measurement: no wait for the refill -- garbage)
       __builtin_amdgcn_s_barrier();
 #ifdef VA_PROBES
       if (gb == 0) { PP_STAMP(1, __builtin_amdgcn_s_memrealtime()); PP_STAMP(5, __builtin_amdgcn_s_memtime()); }
