@@ -360,3 +360,49 @@ def test_unified_decode_longest_first_order(oracle, fp8, shape):
         _lib.set_tuning("pa_order", 1)
         torch.cuda.synchronize()
         assert torch.equal(outs[0], outs[1])
+
+
+@pytest.fixture
+def force_fa():
+    """The 256-row kernel (prefill_fa.hip) for every launch that it supports ("pf_fa" = 2), not only long chunks."""
+    from vllm_amd import _lib
+    _lib.set_tuning("pf_fa", 2)
+    yield
+    _lib.set_tuning("pf_fa", 0)
+
+
+@pytest.mark.parametrize("heads", [(8, 2), (32, 8), (4, 4), (6, 2), (14, 2), (16, 1), (24, 1)])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("seq_lens", [[(700, 700), (300, 1500), (64, 64), (1, 1)],
+                                      [(257, 1000), (130, 131), (1, 900), (5, 18), (63, 64), (65, 65)]])
+def test_unified_fa_kernel(oracle, force_fa, heads, fp8, dtype, seq_lens):
+    """The 256-row kernel on every GQA packing (groups that divide 256 rows, 3 and 7 that do not, 24 = unpacked
+    rows): pure and chunked prefill, row blocks with one valid row, interior / diagonal / skipped tiles, stale NaN
+    slots behind the sequences, both cache types."""
+    c = make_unified_case(seq_lens, heads[0], heads[1], 128, 16, dtype, fp8=fp8, seed=heads[0] + len(seq_lens),
+                          kv_scale=0.5)
+    run(oracle, c, dtype, fp8=fp8)
+
+
+@pytest.mark.parametrize("mode", ["fp8_out", "hnd", "bs64", "mixed16"])
+@pytest.mark.parametrize("fp8", [False, True])
+def test_unified_fa_kernel_features(oracle, force_fa, mode, fp8):
+    """fp8 output, a head-major cache allocation, 64-token pages, and a batch of >= 16 sequences whose decode tokens
+    go to the decode kernel while the 256-row kernel skips them."""
+    seqs = [(200, 900), (1, 77), (33, 33), (400, 400)]
+    if mode == "mixed16":
+        seqs = seqs + [(1, 100 + 37 * i) for i in range(14)]
+    c = make_unified_case(seqs, 8, 2, 128, 64 if mode == "bs64" else 16, torch.bfloat16, fp8=fp8, seed=11, kv_scale=0.75)
+    view = (lambda t: t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)) if mode == "hnd" else None
+    run(oracle, c, torch.bfloat16, fp8=fp8, out_scale=torch.tensor([0.03]) if mode == "fp8_out" else None, view=view)
+
+
+def test_unified_fa_kernel_sharp_rows(oracle, force_fa):
+    """Rows whose maximum keeps growing along the keys (the lazy rescale must fire on some tiles and not on others):
+    keys scaled up with their position."""
+    c = make_unified_case([(300, 1200)], 8, 2, 128, 16, torch.bfloat16, seed=3)
+    bt = c["block_table"][0]
+    for t in range(1200):
+        c["k"][int(bt[t // 16]), t % 16] *= (0.2 + 2.5 * t / 1200)
+    run(oracle, c, torch.bfloat16)

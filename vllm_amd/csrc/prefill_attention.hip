@@ -18,6 +18,7 @@
 // next tile's global loads in flight during the MFMAs.
 #include "mma.cuh"
 #include "unified_decode.cuh"
+#include "prefill_fa.cuh"
 
 #include <float.h>
 #include <type_traits>
@@ -27,6 +28,7 @@ namespace va {
 constexpr int PF_BN = 64;
 int g_pf_rows = 0;   // tuning "pf_rows": query rows per workgroup (0 = default)
 int g_uni_decode = 1;   // tuning "uni_decode": 0 = decode-only launches take the packed tile kernel
+int g_pf_fa = 0;        // tuning "pf_fa": 1 = unified_attention never takes the 256-row kernel (prefill_fa.hip), 2 = whenever it can
 
 struct PrefillParams {
   void* o; const void* q; const void* k; const void* v;
@@ -804,6 +806,28 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
       const int rc = unified_decode(u);
       if (!mixed || rc != VLLM_AMD_OK) return rc;
       p.skip_decode = 1;
+    }
+  }
+  // Long query chunks at head size 128 with only the causal mask: the 256-row kernel (prefill_fa.hip; rows =
+  // (token, q head of the group) pairs when the group divides into 256 rows).  "Long" = the longest chunk
+  // fills at least one of its row blocks.
+  {
+    const int pack = (gqa > 1 && gqa <= 16) ? gqa : 1;
+    const bool can = head_size == 128 && p.alibi_slopes == nullptr && p.softcap == 0.f && p.sliding_window == 0 &&
+                     p.flat_batch > 0 && p.sm_scale > 0.f && g_pf_rows == 0;
+    if (can && g_pf_fa != 1 && (g_pf_fa == 2 || max_q >= 256 / pack)) {
+      FaParams f;
+      f.o = p.o; f.q = p.q; f.k_cache = p.k_cache; f.v_cache = p.v_cache;
+      f.block_table = p.b_loc; f.cu_seqlens_q = p.b_start_loc; f.seq_lens = p.b_seq_len;
+      f.k_scale = p.k_scale; f.v_scale = p.v_scale; f.out_scale = p.fp8_out_scale;
+      f.num_heads = p.num_heads; f.num_kv_heads = p.num_kv_heads; f.num_seqs = batch; f.num_tokens = num_tokens;
+      f.bs_shift = p.bs_shift; f.skip_decode = p.skip_decode; f.pack = pack;
+      f.bt_stride = p.b_loc_stride; f.q_stride_t = p.q_stride_t; f.q_stride_h = p.q_stride_h;
+      f.o_stride_t = p.o_stride_t; f.o_stride_h = p.o_stride_h;
+      f.kc_block_bytes = p.kc_block_bytes; f.kc_slot_bytes = p.kc_page_bytes; f.kc_head_bytes = p.kc_head_bytes;
+      f.vc_block_bytes = p.vc_block_bytes; f.vc_slot_bytes = p.vc_page_bytes; f.vc_head_bytes = p.vc_head_bytes;
+      f.sm_scale = p.sm_scale;
+      return launch_unified_fa(f, std::is_same<T, f16_t>::value ? VLLM_AMD_F16 : VLLM_AMD_BF16, FP8, st);
     }
   }
   // GQA: rows = (token, q head of the group) pairs, grid.y = kv heads ("pf_rows" = 1: off)

@@ -1,0 +1,26 @@
+// unified_attention, long query chunks at head size 128: the 256-row tile kernel of prefill_fa.hip
+// (launched from prefill_attention.hip's launch_unified when its conditions hold).
+#pragma once
+#include "common.cuh"
+
+namespace va {
+
+struct FaParams {
+  void* o; const void* q;
+  const uint8_t* k_cache; const uint8_t* v_cache;        // flash layout [block][slot][kv head][d], any strides
+  const int* block_table; const int* cu_seqlens_q; const int* seq_lens;
+  const float* k_scale; const float* v_scale;             // fp8 cache only
+  const float* out_scale;                                  // != null: e4m3 output
+  int num_heads, num_kv_heads, num_seqs, num_tokens;
+  int bs_shift;        // log2(block size)
+  int skip_decode;     // sequences of query length 1 were taken by the decode kernel
+  int pack;            // q heads per tile-row group: the GQA group (rows = (token, head) pairs) or 1
+  int64_t bt_stride, q_stride_t, q_stride_h, o_stride_t, o_stride_h;
+  int64_t kc_block_bytes, kc_slot_bytes, kc_head_bytes, vc_block_bytes, vc_slot_bytes, vc_head_bytes;
+  float sm_scale;
+};
+
+// dtype: VLLM_AMD_F16 / VLLM_AMD_BF16 (queries, output, and the cache unless fp8)
+int launch_unified_fa(const FaParams& p, int dtype, bool fp8, hipStream_t st);
+
+}  // namespace va
