@@ -13,11 +13,15 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--unified", action="store_true", help="unified_attention over a flash-layout cache")
 ap.add_argument("--rows", type=int, default=0, help="query rows per workgroup (tuning pf_rows)")
 ap.add_argument("--hnd", action="store_true", help="unified: head-major cache memory (permuted view)")
+ap.add_argument("--set", default="", help="tuning keys: k=v[,k=v]")
 ap.add_argument("--fa", type=int, default=0, help="tuning pf_fa: 1 = never the 256-row kernel, 2 = always")
 a = ap.parse_args()
 if a.fa:
     from vllm_amd import _lib
     _lib.set_tuning("pf_fa", a.fa)
+for kv_ in filter(None, a.set.split(",")):
+    from vllm_amd import _lib
+    _lib.set_tuning(kv_.split("=")[0], int(kv_.split("=")[1]))
 dev = torch.device("cuda", 0)
 if a.rows:
     from vllm_amd import _lib

@@ -35,6 +35,8 @@ extern int g_cache_hpw;
 extern int g_pf_rows;   // prefill_attention.hip
 extern int g_uni_decode;
 extern int g_pf_fa;
+extern int g_pf_fa_stagger;
+extern int g_pf_fa_abl;
 
 template <typename cache_t> struct CacheTraits;
 template <> struct CacheTraits<float> { static constexpr int X = 4; };
@@ -582,6 +584,8 @@ extern "C" int vllm_amd_set_tuning(const char* key, int value) {
   if (strcmp(key, "pf_rows") == 0) { g_pf_rows = value; return VLLM_AMD_OK; }
   if (strcmp(key, "uni_decode") == 0) { g_uni_decode = value; return VLLM_AMD_OK; }
   if (strcmp(key, "pf_fa") == 0) { g_pf_fa = value; return VLLM_AMD_OK; }
+  if (strcmp(key, "pf_fa_abl") == 0) { g_pf_fa_abl = value; return VLLM_AMD_OK; }
+  if (strcmp(key, "pf_fa_stagger") == 0) { g_pf_fa_stagger = value; return VLLM_AMD_OK; }
   VA_REQUIRE(false, VLLM_AMD_EINVAL, "set_tuning: unknown key %s", key);
 }
 

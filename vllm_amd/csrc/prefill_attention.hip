@@ -28,6 +28,8 @@ namespace va {
 constexpr int PF_BN = 64;
 int g_pf_rows = 0;   // tuning "pf_rows": query rows per workgroup (0 = default)
 int g_uni_decode = 1;   // tuning "uni_decode": 0 = decode-only launches take the packed tile kernel
+extern int g_pf_fa_stagger;   // prefill_fa.hip
+int g_pf_fa_abl = 0;    // tuning "pf_fa_abl": measurement only, see prefill_fa.cuh
 int g_pf_fa = 0;        // tuning "pf_fa": 1 = unified_attention never takes the 256-row kernel (prefill_fa.hip), 2 = whenever it can
 
 struct PrefillParams {
@@ -827,6 +829,8 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
       f.kc_block_bytes = p.kc_block_bytes; f.kc_slot_bytes = p.kc_page_bytes; f.kc_head_bytes = p.kc_head_bytes;
       f.vc_block_bytes = p.vc_block_bytes; f.vc_slot_bytes = p.vc_page_bytes; f.vc_head_bytes = p.vc_head_bytes;
       f.sm_scale = p.sm_scale;
+      f.abl = g_pf_fa_abl;
+      f.stagger = g_pf_fa_stagger;
       return launch_unified_fa(f, std::is_same<T, f16_t>::value ? VLLM_AMD_F16 : VLLM_AMD_BF16, FP8, st);
     }
   }

@@ -18,6 +18,9 @@ struct FaParams {
   int64_t bt_stride, q_stride_t, q_stride_h, o_stride_t, o_stride_h;
   int64_t kc_block_bytes, kc_slot_bytes, kc_head_bytes, vc_block_bytes, vc_slot_bytes, vc_head_bytes;
   float sm_scale;
+  int stagger;         // 1 = waves 4-7 stage at the top of the interval (tuning "pf_fa_stagger", default 1)
+  int abl;             // (unused; the kernel's ablations are compile-time: -DVA_FA_ABL=bits, garbage results: 1 no exp2,
+                       // 2 no staging after the first tiles, 4 no S^T MFMAs, 8 no PV MFMAs, 16 no barrier)
 };
 
 // dtype: VLLM_AMD_F16 / VLLM_AMD_BF16 (queries, output, and the cache unless fp8)

@@ -53,7 +53,9 @@ template <> struct Mma32<f16_t> {
 constexpr int BM = 256, BN = 64, D = 128, NW = 8;
 constexpr int ROWB = 2 * D;       // bytes per LDS row (one key, 128 16-bit values)
 constexpr int TILE = BN * ROWB;   // 16 KiB
-constexpr int K_OFF = 0, V_OFF = 2 * TILE;
+constexpr int KN = 2, VN = 2;     // K / V tiles in LDS (rings indexed by the tile number)
+constexpr int KR = 8, VR = 4;     // fragment reads in flight: K reads, V^T fragments (two transposing reads each)
+constexpr int K_OFF = 0, V_OFF = KN * TILE;
 constexpr float THR = 8.f;        // lazy rescale threshold (log2 domain)
 
 __device__ __forceinline__ float max3(float a, float b, float c) {
@@ -83,12 +85,38 @@ __device__ __forceinline__ u32x2 lds_tr16(const uint8_t* p) {
   return __builtin_bit_cast(u32x2, v);
 }
 
+// -DVA_PROBES (tools/fa_stamps.py): shader-clock time per wave spent in each part of the tile loop, summed over
+// the wave's tiles: 0 K ring fill + staging (LDS writes of tile t + 1, loads of t + 2), 2 S^T, 4 softmax + PV,
+// 5 barrier, 6 tiles computed, 7 whole kernel
+#ifdef VA_PROBES
+__device__ unsigned long long g_fa_stamps[2048 * 8 * 8];
+#define FA_T(i)                                                   \
+  do {                                                            \
+    const unsigned long long now__ = __builtin_readcyclecounter(); \
+    acc__[i] += now__ - last__;                                   \
+    last__ = now__;                                               \
+  } while (0)
+#else
+#define FA_T(i) do { } while (0)
+#endif
+
 template <typename T, bool FP8>
 __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * TILE];   // K0 K1 V0 V1
+  __shared__ __attribute__((aligned(16))) uint8_t lds[(KN + VN) * TILE];   // 96 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, hi = lane >> 5;
+  // ablations are compile-time (-DVA_FA_ABL=n, tools/fa_stamps.sh; bits in prefill_fa.cuh): a run-time branch
+  // around every MFMA costs the schedule it is meant to measure
+#ifndef VA_FA_ABL
+#define VA_FA_ABL 0
+#endif
+  constexpr int abl = VA_FA_ABL;
+#ifdef VA_PROBES
+  unsigned long long acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_entry__ = __builtin_readcyclecounter();
+  unsigned long long last__ = t_entry__;
+#endif
 
   // ---- workgroup -> (row block of some sequence, head).  Hardware ids go round-robin over the XCDs: the
   // bijective remap gives every XCD a contiguous range of logical ids (row blocks fastest, then heads), so the
@@ -178,9 +206,10 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   uint8_t* v_wr = lds + V_OFF + skey * ROWB;
   const int kc0 = ((2 * spiece) ^ (skey & 15)) << 4, kc1 = ((2 * spiece + 1) ^ (skey & 15)) << 4;
   const int vc0 = ((2 * spiece) ^ ((skey & 3) << 2)) << 4, vc1 = ((2 * spiece + 1) ^ ((skey & 3) << 2)) << 4;
-  auto write_tile = [&](int t, int buf) __attribute__((always_inline)) {
-    // slots past the sequence hold stale bytes (possibly NaN): V rows of such keys are zeroed (their
-    // probabilities are 0, and 0 * NaN = NaN); K rows give scores that the mask replaces
+  auto write_tile = [&](int t) __attribute__((always_inline)) {
+    const int kb_ = (t & (KN - 1)) * TILE, vb_ = (t & (VN - 1)) * TILE;
+    // slots past the sequence hold stale bytes (possibly NaN): K and V rows of such keys are zeroed (their
+    // scores are 0 + the mask's -inf, their probabilities 0, and 0 * NaN = NaN)
     const bool live = t * BN + skey < seq_len;
     u32x4 k0, k1, v0, v1;
     if constexpr (FP8) {
@@ -194,11 +223,11 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
     } else {
       k0 = kst[0]; k1 = kst[NST - 1]; v0 = vst[0]; v1 = vst[NST - 1];
     }
-    if (!live) { v0 = (u32x4){0, 0, 0, 0}; v1 = v0; }
-    *reinterpret_cast<u32x4*>(k_wr + buf * TILE + kc0) = k0;
-    *reinterpret_cast<u32x4*>(k_wr + buf * TILE + kc1) = k1;
-    *reinterpret_cast<u32x4*>(v_wr + buf * TILE + vc0) = v0;
-    *reinterpret_cast<u32x4*>(v_wr + buf * TILE + vc1) = v1;
+    if (!live) { v0 = (u32x4){0, 0, 0, 0}; v1 = v0; k0 = v0; k1 = v0; }
+    *reinterpret_cast<u32x4*>(k_wr + kb_ + kc0) = k0;
+    *reinterpret_cast<u32x4*>(k_wr + kb_ + kc1) = k1;
+    *reinterpret_cast<u32x4*>(v_wr + vb_ + vc0) = v0;
+    *reinterpret_cast<u32x4*>(v_wr + vb_ + vc1) = v1;
   };
 
   // ---- fragment read addresses (lane constants; buffer, key block and key group are immediates) ---------
@@ -223,41 +252,70 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
 
-  // ---- one K / V tile --------------------------------------------------------------------------------------
-  auto compute = [&](auto cur_c, int t, bool masked) __attribute__((always_inline)) {
-    constexpr int cur = decltype(cur_c)::value;
-    f32x16 s[2];
-    static_for<8>([&](auto ksc) {
-      constexpr int ks = decltype(ksc)::value;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const u32x4 kf = *reinterpret_cast<const u32x4*>(k_rd[ks] + cur * TILE + kb * 32 * ROWB);
-        if constexpr (ks == 0) {
-          f32x16 z;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) z[r] = 0.f;
-          s[kb] = Mma32<T>::mfma(kf, qf[0], z);
-        } else {
-          s[kb] = Mma32<T>::mfma(kf, qf[ks], s[kb]);
-        }
-      }
-    });
-    // lane holds S^T[key = 64 t + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi][this row]
-    if (masked) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+  // ---- one K / V tile --------------------------------------------------------------------------------------------
+  // A wave's instruction stream is what bounds this kernel (in-kernel stamps, profiles/r03_prefill_fa.txt: with
+  // every MFMA removed a tile still took 94 % of its time -- LDS fragment reads a fixed short distance ahead of
+  // their use, then the softmax, then the next reads), so the three kinds of work are interleaved inside the
+  // wave, and the sched_barriers keep hipcc from undoing it:
+  //   * fragment reads run a ring ahead of the MFMAs that consume them (8 K reads, 4 V^T fragments); the K ring is
+  //     filled right behind the barrier, IN FRONT of the staging work (LDS writes of tile t + 1, address
+  //     arithmetic and loads of tile t + 2), the V^T ring in front of the serial part of the softmax;
+  //   * S^T is computed key block by key block, the row maximum of block 0 is taken between the MFMAs of block 1;
+  //   * the probabilities of key group g + 1 (exp2, row sum, pack: 7 VALU per MFMA) are computed between the
+  //     four PV MFMAs of group g.
+  // (all per-tile state is local to this lambda: declared outside the tile loop and assigned under `if (active)`
+  // it would be live around the whole loop)
+  auto compute = [&](int t, auto masked_c) __attribute__((always_inline)) {
+  constexpr bool MASKED = decltype(masked_c)::value;
+  f32x16 s[2];
+  u32x4 pb[4];   // P^T fragments of key groups 16 g16 ..: slots 0-3 = keys 4 hi + (0..3), 4-7 = 8 + 4 hi + (0..3)
+  u32x4 kf[KR];
+  const int kofs = (t & (KN - 1)) * TILE;
+  const int vofs = (t & (VN - 1)) * TILE;
+  auto k_read = [&](auto ic, int kofs) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;   // read i -> (key block i >> 3, k-step i & 7)
+    return *reinterpret_cast<const u32x4*>(k_rd[i & 7] + kofs + (i >> 3) * 32 * ROWB);
+  };
+  static_for<KR>([&](auto ic) { kf[decltype(ic)::value] = k_read(ic, kofs); });
+  __builtin_amdgcn_sched_barrier(0);
+  float mx = 0.f;   // running maximum of the tile's raw scores in this lane
+  {
+    static_for<16>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, kb = i >> 3, ks = i & 7;
+      const u32x4 f = kf[i % KR];
+      if constexpr (i + KR < 16) kf[i % KR] = k_read(std::integral_constant<int, i + KR>{}, kofs);
+      if constexpr (ks == 0) {
+        // the accumulator starts at 0, or at -inf where the key is invisible to this row: the mask rides in the
+        // MFMA's C operand (K rows past the sequence are staged as zeros, so nothing there is NaN or inf)
+        f32x16 z;
         const int lim = bound - t * BN - 32 * kb - 4 * hi;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = ((r & 3) + 8 * (r >> 2)) <= lim ? s[kb][r] : -INFINITY;
+        for (int r = 0; r < 16; ++r) z[r] = (!MASKED || ((r & 3) + 8 * (r >> 2)) <= lim) ? 0.f : -INFINITY;
+        s[kb] = Mma32<T>::mfma(f, qf[0], z);
+      } else {
+        if (!(abl & 4)) s[kb] = Mma32<T>::mfma(f, qf[ks], s[kb]);
       }
-    }
-    float mx = max3(s[0][0], s[0][1], s[0][2]);
+      if constexpr (kb == 1) {   // block 0 is complete: its maximum, two scores per MFMA
+        if constexpr (ks == 0) mx = max3(s[0][0], s[0][1], s[0][1]);
+        else mx = max3(mx, s[0][2 * ks], s[0][2 * ks + 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  FA_T(2);
+  u32x4 vf[VR];
+  auto v_read = [&](auto ic, int vofs) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;   // MFMA i -> (key group i >> 2, d block i & 3)
+    const u32x2 va = lds_tr16(v_rd[i & 3] + vofs + (16 * (i >> 2)) * ROWB);
+    const u32x2 vb = lds_tr16(v_rd[i & 3] + vofs + (16 * (i >> 2) + 8) * ROWB);
+    return (u32x4){va[0], va[1], vb[0], vb[1]};
+  };
+  {
+    static_for<VR>([&](auto ic) { vf[decltype(ic)::value] = v_read(ic, vofs); });
+    __builtin_amdgcn_sched_barrier(0);
+    // lane holds S^T[key = 64 t + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi][this row]
 #pragma unroll
-    for (int r = 3; r < 15; r += 2) mx = max3(mx, s[0][r], s[0][r + 1]);
-    mx = max3(mx, s[0][15], s[1][0]);
-#pragma unroll
-    for (int r = 1; r < 15; r += 2) mx = max3(mx, s[1][r], s[1][r + 1]);
-    mx = fmaxf(mx, s[1][15]);
+    for (int r = 0; r < 16; r += 2) mx = max3(mx, s[1][r], s[1][r + 1]);
     const float ms = xmax(mx) * sct;
     if (__any(ms > m_run + THR)) {
       const float m_new = fmaxf(m_run, ms);
@@ -271,62 +329,90 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
     }
     // v_scale rides in the exponent: exp2(s - (m - log2 v_scale)) = p * v_scale
     const float msub = (m_run == -INFINITY ? 0.f : m_run) - vlog2;
-    u32x4 pb[4];   // P^T fragments of key groups 16 g16 ..: slots 0-3 = keys 4 hi + (0..3), 4-7 = 8 + 4 hi + (0..3)
     float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        float e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          e[j] = fast_exp2(fmaf(s[kb][8 * h2 + j], sct, -msub));
-          psum += e[j];
-        }
-        pb[2 * kb + h2] = (u32x4){Mma<T>::pack2(e[0], e[1]), Mma<T>::pack2(e[2], e[3]), Mma<T>::pack2(e[4], e[5]),
-                                  Mma<T>::pack2(e[6], e[7])};
-      }
-    l_run += psum;
+    auto p_word = [&](auto gc, auto jc) __attribute__((always_inline)) {   // word j2 of pb[g16]: two probabilities
+      constexpr int g16 = decltype(gc)::value, j2 = decltype(jc)::value, r0 = 8 * (g16 & 1) + 2 * j2;
+      float e0 = fmaf(s[g16 >> 1][r0], sct, -msub), e1 = fmaf(s[g16 >> 1][r0 + 1], sct, -msub);
+      if (!(abl & 1)) { e0 = fast_exp2(e0); e1 = fast_exp2(e1); }
+      psum += e0;
+      psum += e1;
+      pb[g16][j2] = Mma<T>::pack2(e0, e1);
+    };
+    static_for<4>([&](auto jc) { p_word(std::integral_constant<int, 0>{}, jc); });
+    __builtin_amdgcn_sched_barrier(0);
     // O^T += V^T . P^T
-#pragma unroll
-    for (int g16 = 0; g16 < 4; ++g16)
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const u32x2 va = lds_tr16(v_rd[db] + cur * TILE + (16 * g16) * ROWB);
-        const u32x2 vb = lds_tr16(v_rd[db] + cur * TILE + (16 * g16 + 8) * ROWB);
-        o[db] = Mma32<T>::mfma((u32x4){va[0], va[1], vb[0], vb[1]}, pb[g16], o[db]);
-      }
+    static_for<16>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, g16 = i >> 2, db = i & 3;
+      const u32x4 f = vf[i % VR];
+      if constexpr (i + VR < 16) vf[i % VR] = v_read(std::integral_constant<int, i + VR>{}, vofs);
+      if (!(abl & 8) || i < 4) o[db] = Mma32<T>::mfma(f, pb[g16], o[db]);
+      if constexpr (g16 + 1 < 4) p_word(std::integral_constant<int, g16 + 1>{}, std::integral_constant<int, db>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    l_run += psum;
+  }
   };
 
   // ---- pipeline ------------------------------------------------------------------------------------------------
-  // registers hold tile t + 1 (loads in flight) while tile t is computed from LDS buffer t & 1; they are written
-  // to buffer (t + 1) & 1 -- last read for tile t - 1, before the barrier that ended iteration t - 1 -- after
-  // the softmax, then the loads of tile t + 2 are issued in front of the PV product.
+  // Registers hold tile t + 1 (loads in flight) while tile t is computed from LDS buffer t & 1; in interval t they
+  // are written to buffer (t + 1) & 1 -- last read for tile t - 1, before the barrier that ended interval t - 1 --
+  // and the loads of tile t + 2 are issued.  One barrier per tile.
   int blk = load_blk(0);
   issue_loads(0, blk);
   blk = load_blk(1);
-  write_tile(0, 0);
+  write_tile(0);
   if (1 < ntiles) issue_loads(1, blk);
   blk = load_blk(2);
   __syncthreads();
-  auto iter = [&](auto cur_c, int t) __attribute__((always_inline)) {
-    constexpr int cur = decltype(cur_c)::value;
-    const int n0 = t * BN;
-    const bool active = w_rows && n0 <= w_hi;          // wave-uniform
-    const bool masked = n0 + BN - 1 > w_lo;
-    // (everything a wave does for a tile sits between two barriers; the K / V writes of tile t + 1 go in
-    // front of the compute for waves that skip it)
-    if (t + 1 < ntiles) write_tile(t + 1, cur ^ 1);
-    if (t + 2 < ntiles) issue_loads(t + 2, blk);
-    blk = load_blk(t + 3);
-    if (active) compute(cur_c, t, masked);
-    __syncthreads();
+#ifdef VA_PROBES
+  last__ = __builtin_readcyclecounter();
+#endif
+  // A wave's tiles come in three runs: interior tiles (every key visible to every row of the wave), masked
+  // tiles (the diagonal and the sequence's last tile), tiles above its rows (staging only).  One loop per run:
+  // with both compute copies behind a branch inside one loop hipcc spills 40 registers at the join.
+  // STAGGER: the second wave of every SIMD (waves 4-7) does its share of the staging at the TOP of the interval,
+  // the first one at the bottom: while one wave converts, writes and computes addresses, its partner is in its
+  // MFMA sections (all eight waves in step leave the matrix pipe idle during the staging and collide in it
+  // otherwise: in-kernel stamps showed tile time = MFMA time + everything else, no overlap at all).
+  const bool stage_first = p.stagger && wave >= NW / 2;
+  auto stage = [&](int t) __attribute__((always_inline)) {
+    if (!(abl & 2)) {
+      if (t + 1 < ntiles) write_tile(t + 1);
+      if (t + 2 < ntiles) issue_loads(t + 2, blk);
+      blk = load_blk(t + 3);
+    }
   };
-  for (int t = 0; t < ntiles; t += 2) {
-    iter(std::integral_constant<int, 0>{}, t);
-    if (t + 1 < ntiles) iter(std::integral_constant<int, 1>{}, t + 1);
-  }
+  auto tile_loop = [&](int t_begin, int t_end, auto mode_c) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_c)::value;
+    for (int t = t_begin; t < t_end; ++t) {
+      if (stage_first) stage(t);
+      FA_T(1);
+      if constexpr (MODE < 2) {
+        compute(t, std::integral_constant<bool, MODE == 1>{});
+        FA_T(4);
+#ifdef VA_PROBES
+        acc__[6] += 1;
+#endif
+      }
+      // (behind the compute the fragment rings are dead: room for the conversion temporaries)
+      if (!stage_first) stage(t);
+      FA_T(0);
+      if (!(abl & 16)) __syncthreads();
+      FA_T(5);
+    }
+  };
+  const int t2 = w_rows ? min(w_hi / BN + 1, ntiles) : 0;   // tiles with n0 <= w_hi
+  const int t1 = w_rows ? min((w_lo + 1) / BN, t2) : 0;     // tiles with n0 + 63 <= w_lo
+  tile_loop(0, t1, std::integral_constant<int, 0>{});
+  tile_loop(t1, t2, std::integral_constant<int, 1>{});
+  tile_loop(t2, ntiles, std::integral_constant<int, 2>{});
 
+#ifdef VA_PROBES
+  if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 2048) {
+    acc__[7] = __builtin_readcyclecounter() - t_entry__;
+    for (int i = 0; i < 8; ++i) g_fa_stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = acc__[i];
+  }
+#endif
   // ---- O^T / l -> out ------------------------------------------------------------------------------------------
   if (!rok) return;
   const float l = xsum(l_run);
@@ -358,6 +444,7 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
 
 }  // namespace fa
 
+int g_pf_fa_stagger = 1;   // tuning "pf_fa_stagger": 0 = all eight waves stage at the bottom of the interval
 int launch_unified_fa(const FaParams& p, int dtype, bool fp8, hipStream_t st) {
   const int tpb = fa::BM / p.pack;
   const dim3 grid((unsigned)(p.num_tokens / tpb + p.num_seqs), (unsigned)(p.pack > 1 ? p.num_kv_heads : p.num_heads));
@@ -369,3 +456,9 @@ int launch_unified_fa(const FaParams& p, int dtype, bool fp8, hipStream_t st) {
 }
 
 }  // namespace va
+
+#ifdef VA_PROBES
+extern "C" int vllm_amd_probe_fa_stamps(unsigned long long* dst, int nwg) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(va::fa::g_fa_stamps), (size_t)nwg * 8 * 8 * 8) == hipSuccess ? 0 : -3;
+}
+#endif
