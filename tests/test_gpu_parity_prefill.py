@@ -195,3 +195,65 @@ def test_forward_prefix_wrapper(oracle):
                                         c["b_start_loc"].cuda(), c["b_seq_len"].cuda(),
                                         c["max_input_len"], None, None, one, one)
     torch.testing.assert_close(out.cpu().float(), prefill_reference(c), atol=1.5e-3, rtol=0)
+
+
+@pytest.fixture
+def force_fa():
+    """The 256-row kernel (prefill_fa.hip, PREFIX form) for every launch that it supports ("pf_fa" = 2)."""
+    from vllm_amd import _lib
+    _lib.set_tuning("pf_fa", 2)
+    yield
+    _lib.set_tuning("pf_fa", 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("block_size", [16, 32])
+@pytest.mark.parametrize("heads", [(4, 4), (4, 1), (8, 1), (6, 2), (24, 1)])
+def test_prefill_fa_kernel(oracle, force_fa, dtype, kv, block_size, heads):
+    """The 256-row kernel on the prefix layout: a one-token sequence, pure prefill, contexts that end inside a tile and
+    on a tile boundary, several row blocks per sequence; GQA groups that divide 256 rows, one that does not (3) and
+    unpacked rows (24)."""
+    c = make_prefill_case([1, 150, 77, 128, 300, 64], [200, 0, 131, 64, 500, 1], heads[0], heads[1], 128, block_size,
+                          dtype, kv, seed=block_size + heads[0], kv_scale=0.02)
+    out = run(c, kv)
+    assert not out.isnan().any()
+    torch.testing.assert_close(out.float(), run_oracle(oracle, c, kv).float(), atol=tol(dtype), rtol=0)
+    torch.testing.assert_close(out.float(), prefill_reference(c), atol=tol(dtype), rtol=0)
+
+
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+def test_prefill_fa_kernel_features(oracle, force_fa, kv):
+    """skip_decode, fp8 output, and a launch without num_tokens through the C ABI (grid = blocks per sequence x batch)."""
+    import ctypes
+    from vllm_amd import _lib
+    c = make_prefill_case([1, 90, 1, 260], [64, 70, 5, 129], 8, 2, 128, 16, torch.bfloat16, kv, seed=21, kv_scale=0.02)
+    ref = run_oracle(oracle, c, kv)
+    out = run(c, kv, skip_decode=True)
+    cu = c["b_start_loc"].tolist()
+    for i, ql in enumerate([1, 90, 1, 260]):
+        if ql > 1:
+            torch.testing.assert_close(out[cu[i]:cu[i + 1]].float(), ref[cu[i]:cu[i + 1]].float(), atol=6e-3, rtol=0)
+        else:
+            assert float(out[cu[i]:cu[i + 1]].abs().max()) == 0.0
+    sc8 = torch.tensor([0.02])
+    o8 = run(c, kv, fp8_out_scale=sc8.cuda())
+    r8 = run_oracle(oracle, c, kv, fp8_out_scale=sc8)
+    a = o8.view(torch.float8_e4m3fn).float() * 0.02
+    b = r8.view(torch.float8_e4m3fn).float() * 0.02
+    torch.testing.assert_close(a, b, atol=8e-3 + 6e-3, rtol=0.13)
+    # num_tokens = 0: the kernel cannot enumerate the row blocks of all sequences
+    d = {k: v.cuda() for k, v in c.items() if torch.is_tensor(v)}
+    o = torch.zeros_like(d["q"])
+    q, k, v, kc, vc = d["q"], d["k"], d["v"], d["k_cache"], d["v_cache"]
+    bl, bs, bsl = d["b_loc"].int(), d["b_start_loc"].int(), d["b_seq_len"].int()
+    sc = d["scale"]
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = _lib.lib.vllm_amd_context_attention_fwd(
+        P(o), P(q), P(k), P(v), P(kc), P(vc), P(bl), P(bs), P(bsl), P(sc), P(sc), None, None, 4, 8, 2, 128, 16,
+        c["max_input_len"], bl.stride(0), q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+        o.stride(0), o.stride(1), kc.stride(0), kc.stride(1), vc.stride(0), vc.stride(1), float(128 ** -0.5), 0, 0, 0,
+        _lib.BF16, _lib.KV_FP8_E4M3 if kv == "fp8" else _lib.KV_AUTO, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    torch.testing.assert_close(o.cpu().float(), ref.float(), atol=6e-3, rtol=0)

@@ -829,6 +829,8 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
       f.kc_block_bytes = p.kc_block_bytes; f.kc_slot_bytes = p.kc_page_bytes; f.kc_head_bytes = p.kc_head_bytes;
       f.vc_block_bytes = p.vc_block_bytes; f.vc_slot_bytes = p.vc_page_bytes; f.vc_head_bytes = p.vc_head_bytes;
       f.sm_scale = p.sm_scale;
+      f.prefix = 0; f.k_new = f.v_new = nullptr; f.k_stride_t = f.k_stride_h = f.v_stride_t = f.v_stride_h = 0;
+      f.blocks_per_seq = 0;
       f.abl = g_pf_fa_abl;
       f.stagger = g_pf_fa_stagger;
       return launch_unified_fa(f, std::is_same<T, f16_t>::value ? VLLM_AMD_F16 : VLLM_AMD_BF16, FP8, st);
@@ -878,6 +880,35 @@ static void launch_bs(const PrefillParams& p, int block_size, int max_input_len,
 template <typename T, bool FP8>
 static void launch_d(const PrefillParams& p, int head_size, int block_size, int max_input_len,
                      int num_heads, int batch, hipStream_t st) {
+  // Long chunks at head size 128 with only the causal mask: the 256-row kernel (prefill_fa.hip, PREFIX form)
+  {
+    const int gqa = p.num_heads / p.num_kv_heads;
+    const int pack = (gqa > 1 && gqa <= 16) ? gqa : 1;
+    const bool can = head_size == 128 && p.alibi_slopes == nullptr && p.sliding_window == 0 && p.sm_scale > 0.f &&
+                     g_pf_rows == 0 && (block_size & (block_size - 1)) == 0;
+    if (can && g_pf_fa != 1 && (g_pf_fa == 2 || max_input_len >= 256 / pack)) {
+      FaParams f;
+      f.o = p.o; f.q = p.q; f.k_cache = p.k_cache; f.v_cache = p.v_cache;
+      f.block_table = p.b_loc; f.cu_seqlens_q = p.b_start_loc; f.seq_lens = p.b_seq_len;
+      f.k_scale = p.k_scale; f.v_scale = p.v_scale; f.out_scale = p.fp8_out_scale;
+      f.num_heads = p.num_heads; f.num_kv_heads = p.num_kv_heads; f.num_seqs = batch; f.num_tokens = p.flat_tokens;
+      f.bs_shift = 0;
+      while ((1 << f.bs_shift) < block_size) ++f.bs_shift;
+      f.skip_decode = p.skip_decode; f.pack = pack;
+      f.bt_stride = p.b_loc_stride; f.q_stride_t = p.q_stride_t; f.q_stride_h = p.q_stride_h;
+      f.o_stride_t = p.o_stride_t; f.o_stride_h = p.o_stride_h;
+      f.kc_block_bytes = p.kc_block_bytes; f.kc_slot_bytes = 0; f.kc_head_bytes = p.kc_head_bytes;
+      f.vc_block_bytes = p.vc_block_bytes; f.vc_slot_bytes = 0; f.vc_head_bytes = p.vc_head_bytes;
+      f.sm_scale = p.sm_scale;
+      f.prefix = 1; f.k_new = p.k; f.v_new = p.v;
+      f.k_stride_t = p.k_stride_t; f.k_stride_h = p.k_stride_h; f.v_stride_t = p.v_stride_t; f.v_stride_h = p.v_stride_h;
+      const int tpb = 256 / pack;
+      f.blocks_per_seq = p.flat_batch > 0 ? 0 : (max_input_len + tpb - 1) / tpb;
+      f.abl = 0; f.stagger = g_pf_fa_stagger;
+      launch_unified_fa(f, std::is_same<T, f16_t>::value ? VLLM_AMD_F16 : VLLM_AMD_BF16, FP8, st);
+      return;
+    }
+  }
   switch ((head_size + 31) / 32 * 32) {   // padded to the MFMA K step
     case 32: launch_bs<T, FP8, 32>(p, block_size, max_input_len, num_heads, batch, st); break;
     case 64: launch_bs<T, FP8, 64>(p, block_size, max_input_len, num_heads, batch, st); break;

@@ -7,7 +7,7 @@ namespace va {
 
 struct FaParams {
   void* o; const void* q;
-  const uint8_t* k_cache; const uint8_t* v_cache;        // flash layout [block][slot][kv head][d], any strides
+  const uint8_t* k_cache; const uint8_t* v_cache;        // flash layout [block][slot][kv head][d], any strides (prefix: below)
   const int* block_table; const int* cu_seqlens_q; const int* seq_lens;
   const float* k_scale; const float* v_scale;             // fp8 cache only
   const float* out_scale;                                  // != null: e4m3 output
@@ -18,6 +18,12 @@ struct FaParams {
   int64_t bt_stride, q_stride_t, q_stride_h, o_stride_t, o_stride_h;
   int64_t kc_block_bytes, kc_slot_bytes, kc_head_bytes, vc_block_bytes, vc_slot_bytes, vc_head_bytes;
   float sm_scale;
+  // context_attention_fwd (prefix = 1): the caches are the paged CONTEXT in the x layout -- K [block][kv head][D / x][BS][x]
+  // (x = 16 bytes), V [block][kv head][D][BS]; kc / vc_slot_bytes unused -- and the new tokens' keys / values are dense
+  int prefix;
+  const void* k_new; const void* v_new;
+  int64_t k_stride_t, k_stride_h, v_stride_t, v_stride_h;   // elements
+  int blocks_per_seq;  // > 0: num_tokens unknown, grid.x = blocks_per_seq * num_seqs (ceil(max query length / tokens per block))
   int stagger;         // 1 = waves 4-7 stage at the top of the interval (tuning "pf_fa_stagger", default 1)
   int abl;             // (unused; the kernel's ablations are compile-time: -DVA_FA_ABL=bits, garbage results: 1 no exp2,
                        // 2 no staging after the first tiles, 4 no S^T MFMAs, 8 no PV MFMAs, 16 no barrier)

@@ -100,7 +100,12 @@ __device__ unsigned long long g_fa_stamps[2048 * 8 * 8];
 #define FA_T(i) do { } while (0)
 #endif
 
-template <typename T, bool FP8>
+// PREFIX = context_attention_fwd (vllm/attention/ops/prefix_prefill.py:36-288, 726-913): the keys are the sequence's
+// cached context -- K [block][kv head][D / x][BS][x] (x = 16 bytes), V [block][kv head][D][BS], every cached token
+// visible -- followed by the new tokens' dense k / v (causal).  Context V is already V^T: its tile is staged as
+// [d][token] (8-byte units XOR-swizzled by d >> 1) and the PV MFMA's A operand is two plain 8-byte reads; the new
+// tokens take the unified path's row-major image and transposing reads.  Dense k / v are never fp8.
+template <typename T, bool FP8, bool PREFIX>
 __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[(KN + VN) * TILE];   // 96 KiB
   const int tid = threadIdx.x, lane = tid & 63;
@@ -132,8 +137,11 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   const int pack = p.pack, tpb = BM / pack;   // tokens per workgroup
   // grid.x enumerates the row blocks of ALL sequences (num_tokens / tpb + num_seqs is an upper bound); the
   // sequence is the last one whose first block cu[i] / tpb + i is <= g (find_seq_idx, :33-48)
+  // (blocks_per_seq > 0: the caller did not say how many query tokens there are; every sequence gets that many blocks)
   int seq = 0;
-  {
+  if (p.blocks_per_seq > 0) {
+    seq = g / p.blocks_per_seq;
+  } else {
     int lo = 0, hi2 = p.num_seqs;
     while (hi2 - lo > 1) {
       const int mid = (lo + hi2) >> 1;
@@ -145,7 +153,8 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   const int qlen = p.cu_seqlens_q[seq + 1] - tok0;
   const int seq_len = p.seq_lens[seq];
   const int ctx = seq_len - qlen;
-  const int tok_base = (g - (tok0 / tpb + seq)) * tpb;   // first query token of this block
+  // first query token of this block
+  const int tok_base = (p.blocks_per_seq > 0 ? g % p.blocks_per_seq : g - (tok0 / tpb + seq)) * tpb;
   if (tok_base >= qlen) return;
   if (p.skip_decode && qlen == 1) return;
   const int new_end = min(tok_base + tpb, qlen);
@@ -156,7 +165,10 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   const int rtok = tok_base + mloc / pack;
   const int rhead = pack > 1 ? kvh * pack + mloc % pack : y;
   const bool rok = mloc < tpb * pack && rtok < qlen;
-  const int bound = rok ? ctx + rtok : -1;   // last visible key
+  // last visible key: among the new-domain keys (UNI: every key, by position; PREFIX: the new tokens, by index) and
+  // among the context keys (PREFIX)
+  const int bound_new = rok ? (PREFIX ? rtok : ctx + rtok) : -1;
+  const int bound_ctx = rok ? ctx - 1 : -1;
   // Q^T fragments (B operand of S^T): column m = this row, k = d = 16 ks + 8 hi + (0..7)
   u32x4 qf[8];
   {
@@ -169,65 +181,136 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   }
   // wave-uniform: the tokens of the wave's rows
   const bool w_rows = 32 * wave < tpb * pack && tok_base + (32 * wave) / pack < qlen;
-  const int w_lo = ctx + tok_base + (32 * wave) / pack;
-  const int w_hi = ctx + min(tok_base + (32 * wave + 31) / pack, new_end - 1);
+  const int w_lo = (PREFIX ? 0 : ctx) + tok_base + (32 * wave) / pack;
+  const int w_hi = (PREFIX ? 0 : ctx) + min(tok_base + (32 * wave + 31) / pack, new_end - 1);
 
   float kscale = 1.f, vscale = 1.f;
   if constexpr (FP8) { kscale = *p.k_scale; vscale = *p.v_scale; }
-  const float sct = p.sm_scale * kLog2e * kscale;   // > 0 (host checks sm_scale)
-  const float vlog2 = FP8 ? log2f(vscale) : 0.f;
+  const float sc2 = p.sm_scale * kLog2e;             // > 0 (host checks sm_scale)
+  const float sc2k = sc2 * kscale;                   // fp8 keys: k_scale rides in the score scale
+  const float vlog2 = FP8 ? log2f(vscale) : 0.f, vinv = FP8 ? 1.0f / vscale : 1.f;
 
-  const int ntiles = (ctx + new_end + BN - 1) / BN;
+  // tiles: ctx_tiles of the context (PREFIX), then the new domain's
+  const int ctx_tiles = PREFIX ? (ctx + BN - 1) / BN : 0;
+  const int new_tiles = ((PREFIX ? new_end : ctx + new_end) + BN - 1) / BN;
+  const int ntiles = ctx_tiles + new_tiles;
   const int* bt = p.block_table + (int64_t)seq * p.bt_stride;
-  const int last_page = (seq_len - 1) >> p.bs_shift;
+  const int last_page = PREFIX ? (ctx > 0 ? (ctx - 1) >> p.bs_shift : 0) : (seq_len - 1) >> p.bs_shift;
 
   // ---- staging: thread -> (key = tid >> 3, 32 bytes of 16-bit values = LDS chunks 2 piece, 2 piece + 1) -------
   const int skey = tid >> 3, spiece = tid & 7;
-  constexpr int NST = FP8 ? 1 : 2;
+  constexpr int NST = (FP8 && !PREFIX) ? 1 : 2;
   u32x4 kst[NST], vst[NST];
+  // PREFIX, context V^T: thread -> (d = tid & 127, tokens 16 vq .. of the tile)
+  const int vd = tid & 127, vq = tid >> 7;
+  struct Blk { int k, v; };
   auto load_blk = [&](int t) __attribute__((always_inline)) {
-    return t < ntiles ? bt[min((t * BN + skey) >> p.bs_shift, last_page)] : 0;
+    Blk b = {0, 0};
+    if constexpr (PREFIX) {
+      if (t < ctx_tiles) {
+        b.k = bt[min((t * BN + skey) >> p.bs_shift, last_page)];
+        b.v = bt[min((t * BN + 16 * vq) >> p.bs_shift, last_page)];
+      }
+    } else {
+      if (t < ntiles) b.k = bt[min((t * BN + skey) >> p.bs_shift, last_page)];
+    }
+    return b;
   };
-  auto issue_loads = [&](int t, int blk) __attribute__((always_inline)) {
-    const int slot = (t * BN + skey) & ((1 << p.bs_shift) - 1);
-    const uint8_t* kr = p.k_cache + (int64_t)blk * p.kc_block_bytes + (int64_t)slot * p.kc_slot_bytes +
-                        (int64_t)kvh * p.kc_head_bytes + 16 * NST * spiece;
-    const uint8_t* vr = p.v_cache + (int64_t)blk * p.vc_block_bytes + (int64_t)slot * p.vc_slot_bytes +
-                        (int64_t)kvh * p.vc_head_bytes + 16 * NST * spiece;
+  auto ld16 = [](const void* ptr) __attribute__((always_inline)) { return *reinterpret_cast<const u32x4*>(ptr); };
+  auto issue_loads = [&](int t, Blk blk) __attribute__((always_inline)) {
+    if constexpr (PREFIX) {
+      if (t < ctx_tiles) {
+        const int bsm = (1 << p.bs_shift) - 1;
+        const int slot = (t * BN + skey) & bsm;
+        const uint8_t* kb = p.k_cache + (int64_t)blk.k * p.kc_block_bytes + (int64_t)kvh * p.kc_head_bytes;
+        if constexpr (FP8) {
+          kst[0] = ld16(kb + (((spiece << p.bs_shift) + slot) << 4));
+        } else {
+          kst[0] = ld16(kb + ((((2 * spiece) << p.bs_shift) + slot) << 4));
+          kst[1] = ld16(kb + ((((2 * spiece + 1) << p.bs_shift) + slot) << 4));
+        }
+        const int slot0 = (t * BN + 16 * vq) & bsm;
+        const uint8_t* vb = p.v_cache + (int64_t)blk.v * p.vc_block_bytes + (int64_t)kvh * p.vc_head_bytes +
+                            ((vd << p.bs_shift) + slot0) * (FP8 ? 1 : 2);
+        vst[0] = ld16(vb);
+        if constexpr (!FP8) vst[1] = ld16(vb + 16);
+      } else {
+        const int64_t row = tok0 + min((t - ctx_tiles) * BN + skey, qlen - 1);
+        const T* kr = (const T*)p.k_new + row * p.k_stride_t + (int64_t)kvh * p.k_stride_h + 16 * spiece;
+        const T* vr = (const T*)p.v_new + row * p.v_stride_t + (int64_t)kvh * p.v_stride_h + 16 * spiece;
+        kst[0] = ld16(kr); kst[1] = ld16(kr + 8);
+        vst[0] = ld16(vr); vst[1] = ld16(vr + 8);
+      }
+    } else {
+      const int slot = (t * BN + skey) & ((1 << p.bs_shift) - 1);
+      const uint8_t* kr = p.k_cache + (int64_t)blk.k * p.kc_block_bytes + (int64_t)slot * p.kc_slot_bytes +
+                          (int64_t)kvh * p.kc_head_bytes + 16 * NST * spiece;
+      const uint8_t* vr = p.v_cache + (int64_t)blk.k * p.vc_block_bytes + (int64_t)slot * p.vc_slot_bytes +
+                          (int64_t)kvh * p.vc_head_bytes + 16 * NST * spiece;
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      kst[i] = *reinterpret_cast<const u32x4*>(kr + 16 * i);
-      vst[i] = *reinterpret_cast<const u32x4*>(vr + 16 * i);
+      for (int i = 0; i < NST; ++i) {
+        kst[i] = ld16(kr + 16 * i);
+        vst[i] = ld16(vr + 16 * i);
+      }
     }
   };
   // K image: chunk ^= key & 15 (conflict-free ds_read_b128 of 32 keys x one chunk); V image: chunk ^= (key & 3) << 2
-  // (the four keys of a transposing read land in four different 64-byte bank ranges)
+  // (the four keys of a transposing read land in four different 64-byte bank ranges); context V^T image (PREFIX):
+  // rows of 128 bytes = 64 tokens of one d, 8-byte unit ^= (d >> 1) & 15 (32 rows x one unit: every bank once)
   uint8_t* k_wr = lds + K_OFF + skey * ROWB;
   uint8_t* v_wr = lds + V_OFF + skey * ROWB;
   const int kc0 = ((2 * spiece) ^ (skey & 15)) << 4, kc1 = ((2 * spiece + 1) ^ (skey & 15)) << 4;
   const int vc0 = ((2 * spiece) ^ ((skey & 3) << 2)) << 4, vc1 = ((2 * spiece + 1) ^ ((skey & 3) << 2)) << 4;
+  auto u4 = [](u32x4 v) __attribute__((always_inline)) { return make_uint4(v[0], v[1], v[2], v[3]); };
   auto write_tile = [&](int t) __attribute__((always_inline)) {
     const int kb_ = (t & (KN - 1)) * TILE, vb_ = (t & (VN - 1)) * TILE;
+    const bool is_ctx = PREFIX && t < ctx_tiles;
     // slots past the sequence hold stale bytes (possibly NaN): K and V rows of such keys are zeroed (their
     // scores are 0 + the mask's -inf, their probabilities 0, and 0 * NaN = NaN)
-    const bool live = t * BN + skey < seq_len;
-    u32x4 k0, k1, v0, v1;
-    if constexpr (FP8) {
+    const bool live = PREFIX ? (is_ctx ? t * BN + skey < ctx : (t - ctx_tiles) * BN + skey < qlen)
+                             : t * BN + skey < seq_len;
+    const bool conv = FP8 && (!PREFIX || is_ctx);   // this tile's registers hold e4m3
+    u32x4 k0, k1, v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+    if (conv) {
       uint4 lo, hi4;
-      widen16<T>(make_uint4(kst[0][0], kst[0][1], kst[0][2], kst[0][3]), lo, hi4);
+      widen16<T>(u4(kst[0]), lo, hi4);
       k0 = (u32x4){lo.x, lo.y, lo.z, lo.w};
       k1 = (u32x4){hi4.x, hi4.y, hi4.z, hi4.w};
-      widen16<T>(make_uint4(vst[0][0], vst[0][1], vst[0][2], vst[0][3]), lo, hi4);
-      v0 = (u32x4){lo.x, lo.y, lo.z, lo.w};
-      v1 = (u32x4){hi4.x, hi4.y, hi4.z, hi4.w};
     } else {
-      k0 = kst[0]; k1 = kst[NST - 1]; v0 = vst[0]; v1 = vst[NST - 1];
+      k0 = kst[0]; k1 = kst[NST - 1];
     }
-    if (!live) { v0 = (u32x4){0, 0, 0, 0}; v1 = v0; k0 = v0; k1 = v0; }
+    if (!live) { k0 = (u32x4){0, 0, 0, 0}; k1 = k0; }
     *reinterpret_cast<u32x4*>(k_wr + kb_ + kc0) = k0;
     *reinterpret_cast<u32x4*>(k_wr + kb_ + kc1) = k1;
-    *reinterpret_cast<u32x4*>(v_wr + vb_ + vc0) = v0;
-    *reinterpret_cast<u32x4*>(v_wr + vb_ + vc1) = v1;
+    if (is_ctx) {
+      // V^T: the thread's 16 tokens of row vd = four 8-byte units
+      const int valid = ctx - (t * BN + 16 * vq);
+      uint4 lo, hi4;
+      if constexpr (FP8) {
+        widen16<T>(mask_bytes(u4(vst[0]), valid), lo, hi4);
+      } else {
+        lo = mask_halfs(u4(vst[0]), valid);
+        hi4 = mask_halfs(u4(vst[NST - 1]), valid - 8);
+      }
+      uint8_t* row = lds + V_OFF + vb_ + vd * 128;
+      const int f = (vd >> 1) & 15;
+      *reinterpret_cast<u32x2*>(row + (((4 * vq + 0) ^ f) << 3)) = (u32x2){lo.x, lo.y};
+      *reinterpret_cast<u32x2*>(row + (((4 * vq + 1) ^ f) << 3)) = (u32x2){lo.z, lo.w};
+      *reinterpret_cast<u32x2*>(row + (((4 * vq + 2) ^ f) << 3)) = (u32x2){hi4.x, hi4.y};
+      *reinterpret_cast<u32x2*>(row + (((4 * vq + 3) ^ f) << 3)) = (u32x2){hi4.z, hi4.w};
+    } else {
+      if (conv) {
+        uint4 lo, hi4;
+        widen16<T>(u4(vst[0]), lo, hi4);
+        v0 = (u32x4){lo.x, lo.y, lo.z, lo.w};
+        v1 = (u32x4){hi4.x, hi4.y, hi4.z, hi4.w};
+      } else {
+        v0 = vst[0]; v1 = vst[NST - 1];
+      }
+      if (!live) { v0 = (u32x4){0, 0, 0, 0}; v1 = v0; }
+      *reinterpret_cast<u32x4*>(v_wr + vb_ + vc0) = v0;
+      *reinterpret_cast<u32x4*>(v_wr + vb_ + vc1) = v1;
+    }
   };
 
   // ---- fragment read addresses (lane constants; buffer, key block and key group are immediates) ---------
@@ -244,6 +327,11 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
     for (int db = 0; db < 4; ++db)
       v_rd[db] = lds + V_OFF + (4 * hi + q) * ROWB + ((4 * (db ^ q) + 2 * g1 + (pp >> 1)) << 4) + 8 * (pp & 1);
   }
+
+  // context V^T (PREFIX): row d = 32 db + l32, unit 4 g16 + 2 e + hi = tokens 16 g16 + 8 e + 4 hi .. + 3
+  int vt_o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) vt_o[i] = V_OFF + l32 * 128 + (((2 * i + hi) ^ ((l32 >> 1) & 15)) << 3);
 
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 o[4];   // O^T[d = 32 db + (r & 3) + 8 (r >> 2) + 4 hi][this row]
@@ -265,8 +353,12 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   //     four PV MFMAs of group g.
   // (all per-tile state is local to this lambda: declared outside the tile loop and assigned under `if (active)`
   // it would be live around the whole loop)
-  auto compute = [&](int t, auto masked_c) __attribute__((always_inline)) {
+  auto compute = [&](int t, auto masked_c, auto vt_c) __attribute__((always_inline)) {
   constexpr bool MASKED = decltype(masked_c)::value;
+  constexpr bool VT = decltype(vt_c)::value;               // a context tile of the PREFIX kernel
+  constexpr bool TILE_FP8 = FP8 && (!PREFIX || VT);        // the tile's K / V were e4m3
+  const float sct = TILE_FP8 ? sc2k : sc2;
+  const int bound0 = VT ? bound_ctx - t * BN : bound_new - (t - ctx_tiles) * BN;
   f32x16 s[2];
   u32x4 pb[4];   // P^T fragments of key groups 16 g16 ..: slots 0-3 = keys 4 hi + (0..3), 4-7 = 8 + 4 hi + (0..3)
   u32x4 kf[KR];
@@ -288,7 +380,7 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
         // the accumulator starts at 0, or at -inf where the key is invisible to this row: the mask rides in the
         // MFMA's C operand (K rows past the sequence are staged as zeros, so nothing there is NaN or inf)
         f32x16 z;
-        const int lim = bound - t * BN - 32 * kb - 4 * hi;
+        const int lim = bound0 - 32 * kb - 4 * hi;
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[r] = (!MASKED || ((r & 3) + 8 * (r >> 2)) <= lim) ? 0.f : -INFINITY;
         s[kb] = Mma32<T>::mfma(f, qf[0], z);
@@ -306,9 +398,15 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   u32x4 vf[VR];
   auto v_read = [&](auto ic, int vofs) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;   // MFMA i -> (key group i >> 2, d block i & 3)
-    const u32x2 va = lds_tr16(v_rd[i & 3] + vofs + (16 * (i >> 2)) * ROWB);
-    const u32x2 vb = lds_tr16(v_rd[i & 3] + vofs + (16 * (i >> 2) + 8) * ROWB);
-    return (u32x4){va[0], va[1], vb[0], vb[1]};
+    if constexpr (VT) {
+      const u32x2 va = *reinterpret_cast<const u32x2*>(lds + vt_o[2 * (i >> 2)] + vofs + 4096 * (i & 3));
+      const u32x2 vb = *reinterpret_cast<const u32x2*>(lds + vt_o[2 * (i >> 2) + 1] + vofs + 4096 * (i & 3));
+      return (u32x4){va[0], va[1], vb[0], vb[1]};
+    } else {
+      const u32x2 va = lds_tr16(v_rd[i & 3] + vofs + (16 * (i >> 2)) * ROWB);
+      const u32x2 vb = lds_tr16(v_rd[i & 3] + vofs + (16 * (i >> 2) + 8) * ROWB);
+      return (u32x4){va[0], va[1], vb[0], vb[1]};
+    }
   };
   {
     static_for<VR>([&](auto ic) { vf[decltype(ic)::value] = v_read(ic, vofs); });
@@ -328,7 +426,7 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
     }
     // v_scale rides in the exponent: exp2(s - (m - log2 v_scale)) = p * v_scale
-    const float msub = (m_run == -INFINITY ? 0.f : m_run) - vlog2;
+    const float msub = (m_run == -INFINITY ? 0.f : m_run) - (TILE_FP8 ? vlog2 : 0.f);
     float psum = 0.f;
     auto p_word = [&](auto gc, auto jc) __attribute__((always_inline)) {   // word j2 of pb[g16]: two probabilities
       constexpr int g16 = decltype(gc)::value, j2 = decltype(jc)::value, r0 = 8 * (g16 & 1) + 2 * j2;
@@ -349,7 +447,7 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
       if constexpr (g16 + 1 < 4) p_word(std::integral_constant<int, g16 + 1>{}, std::integral_constant<int, db>{});
       __builtin_amdgcn_sched_barrier(0);
     });
-    l_run += psum;
+    l_run += TILE_FP8 ? psum * vinv : psum;   // the sum in units of the unscaled probabilities
   }
   };
 
@@ -357,7 +455,7 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   // Registers hold tile t + 1 (loads in flight) while tile t is computed from LDS buffer t & 1; in interval t they
   // are written to buffer (t + 1) & 1 -- last read for tile t - 1, before the barrier that ended interval t - 1 --
   // and the loads of tile t + 2 are issued.  One barrier per tile.
-  int blk = load_blk(0);
+  Blk blk = load_blk(0);
   issue_loads(0, blk);
   blk = load_blk(1);
   write_tile(0);
@@ -382,13 +480,13 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
       blk = load_blk(t + 3);
     }
   };
-  auto tile_loop = [&](int t_begin, int t_end, auto mode_c) __attribute__((always_inline)) {
+  auto tile_loop = [&](int t_begin, int t_end, auto mode_c, auto vt_c) __attribute__((always_inline)) {
     constexpr int MODE = decltype(mode_c)::value;
     for (int t = t_begin; t < t_end; ++t) {
       if (stage_first) stage(t);
       FA_T(1);
       if constexpr (MODE < 2) {
-        compute(t, std::integral_constant<bool, MODE == 1>{});
+        compute(t, std::integral_constant<bool, MODE == 1>{}, vt_c);
         FA_T(4);
 #ifdef VA_PROBES
         acc__[6] += 1;
@@ -401,11 +499,22 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
       FA_T(5);
     }
   };
-  const int t2 = w_rows ? min(w_hi / BN + 1, ntiles) : 0;   // tiles with n0 <= w_hi
-  const int t1 = w_rows ? min((w_lo + 1) / BN, t2) : 0;     // tiles with n0 + 63 <= w_lo
-  tile_loop(0, t1, std::integral_constant<int, 0>{});
-  tile_loop(t1, t2, std::integral_constant<int, 1>{});
-  tile_loop(t2, ntiles, std::integral_constant<int, 2>{});
+  constexpr std::integral_constant<int, 0> INTERIOR{};
+  constexpr std::integral_constant<int, 1> MASKED_{};
+  constexpr std::integral_constant<int, 2> SKIP{};
+  // new-domain tiles u = t - ctx_tiles: interior while 64 u + 63 <= w_lo, computed while 64 u <= w_hi
+  const int n2 = w_rows ? min(w_hi / BN + 1, new_tiles) : 0;
+  const int n1 = w_rows ? min((w_lo + 1) / BN, n2) : 0;
+  if constexpr (PREFIX) {
+    // context: whole tiles are interior, the last one (ctx % 64 tokens) is masked
+    const int c2 = w_rows ? ctx_tiles : 0, c1 = w_rows ? ctx / BN : 0;
+    tile_loop(0, c1, INTERIOR, std::true_type{});
+    tile_loop(c1, c2, MASKED_, std::true_type{});
+    tile_loop(c2, ctx_tiles, SKIP, std::true_type{});
+  }
+  tile_loop(ctx_tiles, ctx_tiles + n1, INTERIOR, std::false_type{});
+  tile_loop(ctx_tiles + n1, ctx_tiles + n2, MASKED_, std::false_type{});
+  tile_loop(ctx_tiles + n2, ntiles, SKIP, std::false_type{});
 
 #ifdef VA_PROBES
   if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 2048) {
@@ -416,7 +525,7 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   // ---- O^T / l -> out ------------------------------------------------------------------------------------------
   if (!rok) return;
   const float l = xsum(l_run);
-  const float inv = l > 0.f ? vscale / l : 0.f;   // the sum was taken of the v_scale-scaled probabilities
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
   if (p.out_scale == nullptr) {
     T* op = (T*)p.o + (int64_t)(tok0 + rtok) * p.o_stride_t + (int64_t)rhead * p.o_stride_h + 4 * hi;
 #pragma unroll
@@ -447,8 +556,13 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
 int g_pf_fa_stagger = 1;   // tuning "pf_fa_stagger": 0 = all eight waves stage at the bottom of the interval
 int launch_unified_fa(const FaParams& p, int dtype, bool fp8, hipStream_t st) {
   const int tpb = fa::BM / p.pack;
-  const dim3 grid((unsigned)(p.num_tokens / tpb + p.num_seqs), (unsigned)(p.pack > 1 ? p.num_kv_heads : p.num_heads));
-#define FA_LAUNCH(T_, F_) hipLaunchKernelGGL((fa::fa_fwd_kernel<T_, F_>), grid, dim3(64 * fa::NW), 0, st, p)
+  const unsigned gx = p.blocks_per_seq > 0 ? (unsigned)(p.blocks_per_seq * p.num_seqs) : (unsigned)(p.num_tokens / tpb + p.num_seqs);
+  const dim3 grid(gx, (unsigned)(p.pack > 1 ? p.num_kv_heads : p.num_heads));
+#define FA_LAUNCH(T_, F_)                                                                              \
+  do {                                                                                                 \
+    if (p.prefix) hipLaunchKernelGGL((fa::fa_fwd_kernel<T_, F_, true>), grid, dim3(64 * fa::NW), 0, st, p);  \
+    else hipLaunchKernelGGL((fa::fa_fwd_kernel<T_, F_, false>), grid, dim3(64 * fa::NW), 0, st, p);   \
+  } while (0)
   if (dtype == VLLM_AMD_BF16) { if (fp8) FA_LAUNCH(bf16_t, true); else FA_LAUNCH(bf16_t, false); }
   else { if (fp8) FA_LAUNCH(f16_t, true); else FA_LAUNCH(f16_t, false); }
 #undef FA_LAUNCH
