@@ -428,7 +428,7 @@ def run_fused_neighbours(device, iters=20):
 def run_prefill(device, iters=5):
     """context_attention_fwd (chunked prefill over a paged fp8 prefix) at the
     Llama-3-8B head shape; flops = 4 D H sum_seq q_len (ctx + (q_len + 1) / 2) against the bf16
-    dense MFMA peak."""
+    dense MFMA peak.  Both ops take the 256-row kernel (prefill_fa.hip) at these sizes."""
     from vllm_amd.attention.ops import context_attention_fwd
     H, KVH, D, BS = 32, 8, 128, 16
     out = {}
