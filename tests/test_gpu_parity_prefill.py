@@ -257,3 +257,17 @@ def test_prefill_fa_kernel_features(oracle, force_fa, kv):
     assert rc == 0
     torch.cuda.synchronize()
     torch.testing.assert_close(o.cpu().float(), ref.float(), atol=6e-3, rtol=0)
+
+
+@pytest.mark.parametrize("head_size", [160, 192, 224, 256])
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("gqa", [1, 4])
+def test_prefill_wide_heads(oracle, head_size, kv, gqa):
+    """Head sizes above 128 (the reference's kernel pads any head size to a power of two, prefix_prefill.py:760-790; its
+    backend list goes to 256): the tile kernel's 256-wide instantiation."""
+    c = make_prefill_case([1, 150, 77, 128], [200, 0, 131, 64], 4, 4 // gqa, head_size, 16, torch.bfloat16, kv,
+                          seed=head_size + gqa, kv_scale=0.02)
+    out = run(c, kv)
+    assert not out.isnan().any()
+    torch.testing.assert_close(out.float(), run_oracle(oracle, c, kv).float(), atol=tol(torch.bfloat16), rtol=0)
+    torch.testing.assert_close(out.float(), prefill_reference(c), atol=tol(torch.bfloat16), rtol=0)

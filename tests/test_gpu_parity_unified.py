@@ -57,9 +57,20 @@ def test_unified_reference_grid(oracle, seq_lens, num_heads, block_size, sliding
 
 @pytest.mark.parametrize("D", [160, 192, 224, 256])
 @pytest.mark.parametrize("mode", ["plain", "fp8", "alibi", "fp8_out"])
-def test_unified_wide_heads(oracle, D, mode):
+@pytest.mark.parametrize("kernel", ["tile", "valu"])
+def test_unified_wide_heads(oracle, D, mode, kernel):
     """Head sizes 160 .. 256 of TritonAttentionBackend.get_supported_head_sizes (triton_attn.py:147-148):
-    the wide-head kernel, mixed batch, fp8 cache / ALiBi / fp8 output."""
+    the tile kernel's 256-wide instantiation (default) and the plain VALU kernel ("pf_rows" = 2), mixed batch,
+    fp8 cache / ALiBi / fp8 output."""
+    from vllm_amd import _lib
+    _lib.set_tuning("pf_rows", 2 if kernel == "valu" else 0)
+    try:
+        _wide_heads(oracle, D, mode)
+    finally:
+        _lib.set_tuning("pf_rows", 0)
+
+
+def _wide_heads(oracle, D, mode):
     fp8 = mode in ("fp8", "fp8_out")
     c = make_unified_case([(90, 400), (1, 700), (17, 17), (1, 1), (3, 260)], 8, 2, D, 16, torch.bfloat16,
                           fp8=fp8, seed=D, kv_scale=0.5)

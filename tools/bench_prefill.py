@@ -13,6 +13,7 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--unified", action="store_true", help="unified_attention over a flash-layout cache")
 ap.add_argument("--rows", type=int, default=0, help="query rows per workgroup (tuning pf_rows)")
 ap.add_argument("--hnd", action="store_true", help="unified: head-major cache memory (permuted view)")
+ap.add_argument("--D", type=int, default=128, help="head size")
 ap.add_argument("--set", default="", help="tuning keys: k=v[,k=v]")
 ap.add_argument("--fa", type=int, default=0, help="tuning pf_fa: 1 = never the 256-row kernel, 2 = always")
 a = ap.parse_args()
@@ -26,7 +27,7 @@ dev = torch.device("cuda", 0)
 if a.rows:
     from vllm_amd import _lib
     _lib.set_tuning("pf_rows", a.rows)
-H, KVH, D, BS = 32, 8, 128, 16
+H, KVH, D, BS = 32, 8, a.D, 16
 for (B, ql, cl) in ((4, 2048, 0), (4, 2048, 2048), (1, 8192, 0), (16, 512, 3584), (64, 128, 4096)):
     T = B * ql
     g = torch.Generator(device=dev).manual_seed(0)

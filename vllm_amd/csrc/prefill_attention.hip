@@ -78,10 +78,10 @@ __device__ __forceinline__ uint2 lds_read_tr16(const uint8_t* p) {
 // grid.y = kv heads.  A decode token then streams its K / V once for the whole group (in a
 // batch that mixes prefill chunks and decodes, too).
 template <typename T, bool FP8, int D, int BS, int MT, int NW, bool UNI = false, bool PACK = false>
-__global__ __launch_bounds__(64 * NW, 2) void prefill_kernel(const PrefillParams p) {
+__global__ __launch_bounds__(64 * NW, (D > 128 ? 1 : 2)) void prefill_kernel(const PrefillParams p) {
   static_assert(!PACK || UNI, "");
   constexpr int PF_THREADS = 64 * NW, PF_BM = 16 * MT * NW;
-  static_assert(D % 32 == 0 && D <= 128, "");
+  static_assert(D % 32 == 0 && (D <= 128 || (D == 256 && MT == 1 && NW == 4)), "");   // head sizes 136 .. 256: one configuration
   // D = head size padded to a multiple of 32: chunks at d >= dr are staged as zeros (K, Q: no
   // contribution to the scores; V: output columns that are never stored)
   const int dr = p.head_size;
@@ -714,20 +714,20 @@ __global__ __launch_bounds__(64) void unified_reduce_kernel(const PrefillParams 
   float mx = -INFINITY;
   for (int s2 = 0; s2 < nseg; ++s2) mx = fmaxf(mx, p.segm_max[row + s2]);
   const int dr = p.head_size;
-  float acc[2] = {0.f, 0.f}, l = 0.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, l = 0.f;
   for (int s2 = 0; s2 < nseg; ++s2) {
     const float ms = p.segm_max[row + s2];
     const float w = ms == -INFINITY ? 0.f : fast_exp2(ms - mx);
     l += p.segm_sum[row + s2] * w;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const int d = lane + 64 * j;
       if (d < dr) acc[j] += p.segm_out[(row + s2) * dr + d] * w;
     }
   }
   const float inv = l > 0.f ? 1.0f / l : 0.f;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < 4; ++j) {
     const int d = lane + 64 * j;
     if (d >= dr) continue;
     if (p.fp8_out_scale) {
@@ -854,7 +854,8 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
       p.num_segments = 1;
     }
     if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true, true>(p, 16, rows, p.num_kv_heads, batch, st);
-    else launch_cfg<T, FP8, 128, 1, 4, true, true>(p, 16, rows, p.num_kv_heads, batch, st);
+    else if (head_size <= 128) launch_cfg<T, FP8, 128, 1, 4, true, true>(p, 16, rows, p.num_kv_heads, batch, st);
+    else launch_cfg<T, FP8, 256, 1, 4, true, true>(p, 16, rows, p.num_kv_heads, batch, st);
     if (p.num_segments > 1)
       hipLaunchKernelGGL((unified_reduce_kernel<T>), dim3(num_tokens, num_heads), dim3(64), 0, st, p, tpb,
                          batch);
@@ -862,14 +863,17 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
   }
   p.num_segments = 1;
   if (head_size <= 64) launch_cfg<T, FP8, 64, 2, 4, true>(p, 16, max_q, num_heads, batch, st);
-  else launch_cfg<T, FP8, 128, 1, 4, true>(p, 16, max_q, num_heads, batch, st);
+  else if (head_size <= 128) launch_cfg<T, FP8, 128, 1, 4, true>(p, 16, max_q, num_heads, batch, st);
+  else launch_cfg<T, FP8, 256, 1, 4, true>(p, 16, max_q, num_heads, batch, st);
   return VLLM_AMD_OK;
 }
 template <typename T, bool FP8, int D>
 static void launch_bs(const PrefillParams& p, int block_size, int max_input_len, int num_heads,
                       int batch, hipStream_t st) {
   // head sizes >= 96 do not fit two query tiles per wave in 256 VGPRs without spilling
-  if constexpr (D >= 96) {
+  if constexpr (D > 128) {
+    launch_cfg<T, FP8, D, 1, 4>(p, block_size, max_input_len, num_heads, batch, st);
+  } else if constexpr (D >= 96) {
     if (g_pf_rows == 128) launch_cfg<T, FP8, D, 1, 8>(p, block_size, max_input_len, num_heads, batch, st);
     else launch_cfg<T, FP8, D, 1, 4>(p, block_size, max_input_len, num_heads, batch, st);
   } else {
@@ -913,7 +917,8 @@ static void launch_d(const PrefillParams& p, int head_size, int block_size, int 
     case 32: launch_bs<T, FP8, 32>(p, block_size, max_input_len, num_heads, batch, st); break;
     case 64: launch_bs<T, FP8, 64>(p, block_size, max_input_len, num_heads, batch, st); break;
     case 96: launch_bs<T, FP8, 96>(p, block_size, max_input_len, num_heads, batch, st); break;
-    default: launch_bs<T, FP8, 128>(p, block_size, max_input_len, num_heads, batch, st); break;
+    case 128: launch_bs<T, FP8, 128>(p, block_size, max_input_len, num_heads, batch, st); break;
+    default: launch_bs<T, FP8, 256>(p, block_size, max_input_len, num_heads, batch, st); break;
   }
 }
 
@@ -1118,10 +1123,10 @@ extern "C" int vllm_amd_context_attention_fwd(
     VA_LAUNCH_CHECK(op);
     return VLLM_AMD_OK;
   }
-  VA_REQUIRE(head_size >= 8 && head_size <= 128 &&
+  VA_REQUIRE(head_size >= 8 && head_size <= 256 &&
                  head_size % (kv_cache_dtype == VLLM_AMD_KV_AUTO ? 8 : 16) == 0,
              VLLM_AMD_EUNSUPPORTED,
-             "%s: unsupported head size: %d (multiples of 8, of 16 with an fp8 cache, up to 128)",
+             "%s: unsupported head size: %d (multiples of 8, of 16 with an fp8 cache, up to 256)",
              op, head_size);
   VA_REQUIRE(block_size == 16 || block_size == 32, VLLM_AMD_EUNSUPPORTED,
              "%s: unsupported block size: %d (16, 32)", op, block_size);
@@ -1360,7 +1365,7 @@ extern "C" int vllm_amd_unified_attention(
   p.flat_tokens = num_tokens;
   hipStream_t st = (hipStream_t)stream;
   int rc = VLLM_AMD_OK;
-  if (head_size > 128) {   // the wide-head kernel above
+  if (head_size > 128 && g_pf_rows == 2) {   // the VALU wide-head kernel above ("pf_rows" = 2; the tile kernel takes these sizes)
     const dim3 grid((unsigned)num_tokens, (unsigned)num_heads);
 #define WIDE(T, F) hipLaunchKernelGGL((unified_wide_kernel<T, F>), grid, dim3(256), 0, st, p, num_seqs, head_size, block_size)
     if (dtype == VLLM_AMD_BF16) { if (es == 2) WIDE(bf16_t, false); else WIDE(bf16_t, true); }

@@ -472,7 +472,10 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   // the first one at the bottom: while one wave converts, writes and computes addresses, its partner is in its
   // MFMA sections (all eight waves in step leave the matrix pipe idle during the staging and collide in it
   // otherwise: in-kernel stamps showed tile time = MFMA time + everything else, no overlap at all).
-  const bool stage_first = p.stagger && wave >= NW / 2;
+  const bool stage_first = (p.stagger & 1) && wave >= NW / 2;
+  // ("pf_fa_stagger" bits 1 / 2, measurement: a static priority for waves 4-7 / 0-3)
+  if ((p.stagger & 2) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+  if ((p.stagger & 4) && wave < NW / 2) __builtin_amdgcn_s_setprio(1);
   auto stage = [&](int t) __attribute__((always_inline)) {
     if (!(abl & 2)) {
       if (t + 1 < ntiles) write_tile(t + 1);
