@@ -381,7 +381,7 @@ int vllm_amd_context_attention_fwd(
  *   output_scale  float[1] or NULL: out is e4m3 bytes = clamp(acc / l / scale) (:254-256)
  *   sliding_window = 1 + window_size[0] of the reference call (0 = none) (:655)
  * Supported here: f16 / bf16 queries (no fp8 queries: q_descale is "not supported" in the
- * reference either, :609), head_size a multiple of 8 (16 with an fp8 cache) up to 128,
+ * reference either, :609), head_size a multiple of 8 (16 with an fp8 cache) up to 256,
  * block_size any power of two from 16.  With GQA the tile rows are (token, q head of the group) pairs, so a
  * decode token streams its K / V once per group.  Sequences of query length 1 take a dedicated
  * bandwidth kernel (unified_decode.hip) when the whole launch
