@@ -345,7 +345,7 @@ int vllm_amd_swap_blocks(const void* src, void* dst, int64_t block_bytes,
  *                     blocks for every sequence (mixed batches: few long chunks among many
  *                     one-token sequences launch no empty workgroups)
  * Supported here: f16 / bf16 queries, head_size a multiple of 8 (16 with an fp8 cache) up to
- * 128 (padded to a multiple of 32 inside the kernel), block_size 16/32,
+ * 256 (padded to a multiple of 32, above 128 to 256, inside the kernel), block_size 16/32,
  * kv_cache_dtype auto / fp8_e4m3.  float32 queries (the reference test's second grid,
  * tests/kernels/attention/test_prefix_prefill.py:513-560; cache float32 with x = 4, or fp8):
  * head_size a multiple of 4 (16 with an fp8 cache) up to 256, any block_size, num_tokens
