@@ -417,3 +417,14 @@ def test_unified_fa_kernel_sharp_rows(oracle, force_fa):
     for t in range(1200):
         c["k"][int(bt[t // 16]), t % 16] *= (0.2 + 2.5 * t / 1200)
     run(oracle, c, torch.bfloat16)
+
+
+@pytest.mark.parametrize("window", [1, 16, 64, 100, 257, 1000])
+@pytest.mark.parametrize("heads", [(8, 2), (4, 4), (6, 2)])
+@pytest.mark.parametrize("fp8", [False, True])
+def test_unified_fa_kernel_window(oracle, force_fa, window, heads, fp8):
+    """Sliding windows narrower than a key tile, than a row block's span, and wider: tiles left of the window skipped
+    (not even staged for the workgroup's first rows), left-edge tiles masked, interior, diagonal."""
+    c = make_unified_case([(700, 700), (300, 1500), (64, 64), (1, 900), (130, 131)], heads[0], heads[1], 128, 16,
+                          torch.bfloat16, fp8=fp8, seed=window + heads[0], kv_scale=0.5)
+    run(oracle, c, torch.bfloat16, fp8=fp8, window=window)

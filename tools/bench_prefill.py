@@ -13,6 +13,7 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--unified", action="store_true", help="unified_attention over a flash-layout cache")
 ap.add_argument("--rows", type=int, default=0, help="query rows per workgroup (tuning pf_rows)")
 ap.add_argument("--hnd", action="store_true", help="unified: head-major cache memory (permuted view)")
+ap.add_argument("--window", type=int, default=0, help="unified: sliding window (keys)")
 ap.add_argument("--D", type=int, default=128, help="head size")
 ap.add_argument("--set", default="", help="tuning keys: k=v[,k=v]")
 ap.add_argument("--fa", type=int, default=0, help="tuning pf_fa: 1 = never the 256-row kernel, 2 = always")
@@ -62,7 +63,7 @@ for (B, ql, cl) in ((4, 2048, 0), (4, 2048, 2048), (1, 8192, 0), (16, 512, 3584)
             kf = kf.view(B * nb_u, KVH, BS, D).permute(0, 2, 1, 3)
             vf = vf.view(B * nb_u, KVH, BS, D).permute(0, 2, 1, 3)
         bt = torch.randperm(B * nb_u, device=dev).to(torch.int32).view(B, nb_u)
-        fn = lambda: unified_attention(q, kf, vf, o, start, ql, seql, ql + cl, D ** -0.5, True, (-1, -1),
+        fn = lambda: unified_attention(q, kf, vf, o, start, ql, seql, ql + cl, D ** -0.5, True, ((a.window - 1, 0) if a.window else (-1, -1)),
                                        bt, 0.0, None, one if fp8 else None, one if fp8 else None)
     t = bench.time_gpu_graph(fn, a.iters)
     flops = 4.0 * D * H * B * ql * (cl + (ql + 1) / 2)

@@ -815,7 +815,7 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
   // fills at least one of its row blocks.
   {
     const int pack = (gqa > 1 && gqa <= 16) ? gqa : 1;
-    const bool can = head_size == 128 && p.alibi_slopes == nullptr && p.softcap == 0.f && p.sliding_window == 0 &&
+    const bool can = head_size == 128 && p.alibi_slopes == nullptr && p.softcap == 0.f &&
                      p.flat_batch > 0 && p.sm_scale > 0.f && g_pf_rows == 0;
     if (can && g_pf_fa != 1 && (g_pf_fa == 2 || max_q >= 256 / pack)) {
       FaParams f;
@@ -829,6 +829,7 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
       f.kc_block_bytes = p.kc_block_bytes; f.kc_slot_bytes = p.kc_page_bytes; f.kc_head_bytes = p.kc_head_bytes;
       f.vc_block_bytes = p.vc_block_bytes; f.vc_slot_bytes = p.vc_page_bytes; f.vc_head_bytes = p.vc_head_bytes;
       f.sm_scale = p.sm_scale;
+      f.window = p.sliding_window;
       f.prefix = 0; f.k_new = f.v_new = nullptr; f.k_stride_t = f.k_stride_h = f.v_stride_t = f.v_stride_h = 0;
       f.blocks_per_seq = 0;
       f.abl = g_pf_fa_abl;
@@ -904,6 +905,7 @@ static void launch_d(const PrefillParams& p, int head_size, int block_size, int 
       f.kc_block_bytes = p.kc_block_bytes; f.kc_slot_bytes = 0; f.kc_head_bytes = p.kc_head_bytes;
       f.vc_block_bytes = p.vc_block_bytes; f.vc_slot_bytes = 0; f.vc_head_bytes = p.vc_head_bytes;
       f.sm_scale = p.sm_scale;
+      f.window = 0;
       f.prefix = 1; f.k_new = p.k; f.v_new = p.v;
       f.k_stride_t = p.k_stride_t; f.k_stride_h = p.k_stride_h; f.v_stride_t = p.v_stride_t; f.v_stride_h = p.v_stride_h;
       const int tpb = 256 / pack;

@@ -18,6 +18,7 @@ struct FaParams {
   int64_t bt_stride, q_stride_t, q_stride_h, o_stride_t, o_stride_h;
   int64_t kc_block_bytes, kc_slot_bytes, kc_head_bytes, vc_block_bytes, vc_slot_bytes, vc_head_bytes;
   float sm_scale;
+  int window;          // unified_attention: 1 + window_size[0] of the reference call, 0 = none (prefix: 0)
   // context_attention_fwd (prefix = 1): the caches are the paged CONTEXT in the x layout -- K [block][kv head][D / x][BS][x]
   // (x = 16 bytes), V [block][kv head][D][BS]; kc / vc_slot_bytes unused -- and the new tokens' keys / values are dense
   int prefix;

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
 
   float kscale = 1.f, vscale = 1.f;
   if constexpr (FP8) { kscale = *p.k_scale; vscale = *p.v_scale; }
+  const int window = PREFIX ? 0 : p.window;          // keys (position - window, position] are visible; 0 = all
   const float sc2 = p.sm_scale * kLog2e;             // > 0 (host checks sm_scale)
   const float sc2k = sc2 * kscale;                   // fp8 keys: k_scale rides in the score scale
   const float vlog2 = FP8 ? log2f(vscale) : 0.f, vinv = FP8 ? 1.0f / vscale : 1.f;
@@ -381,8 +382,12 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
         // MFMA's C operand (K rows past the sequence are staged as zeros, so nothing there is NaN or inf)
         f32x16 z;
         const int lim = bound0 - 32 * kb - 4 * hi;
+        const int lim_lo = window > 0 ? lim - window + 1 : -(1 << 30);   // sliding window: keys (bound - window, bound]
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = (!MASKED || ((r & 3) + 8 * (r >> 2)) <= lim) ? 0.f : -INFINITY;
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          z[r] = (!MASKED || (c <= lim && c >= lim_lo)) ? 0.f : -INFINITY;
+        }
         s[kb] = Mma32<T>::mfma(f, qf[0], z);
       } else {
         if (!(abl & 4)) s[kb] = Mma32<T>::mfma(f, qf[ks], s[kb]);
@@ -455,12 +460,14 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   // Registers hold tile t + 1 (loads in flight) while tile t is computed from LDS buffer t & 1; in interval t they
   // are written to buffer (t + 1) & 1 -- last read for tile t - 1, before the barrier that ended interval t - 1 --
   // and the loads of tile t + 2 are issued.  One barrier per tile.
-  Blk blk = load_blk(0);
-  issue_loads(0, blk);
-  blk = load_blk(1);
-  write_tile(0);
-  if (1 < ntiles) issue_loads(1, blk);
-  blk = load_blk(2);
+  // (sliding window: the tiles left of the window of the workgroup's first row are not even staged)
+  const int t_start = window > 0 ? max(ctx + tok_base - window + 1, 0) / BN : 0;
+  Blk blk = load_blk(t_start);
+  issue_loads(t_start, blk);
+  blk = load_blk(t_start + 1);
+  write_tile(t_start);
+  if (t_start + 1 < ntiles) issue_loads(t_start + 1, blk);
+  blk = load_blk(t_start + 2);
   __syncthreads();
 #ifdef VA_PROBES
   last__ = __builtin_readcyclecounter();
@@ -515,9 +522,23 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
     tile_loop(c1, c2, MASKED_, std::true_type{});
     tile_loop(c2, ctx_tiles, SKIP, std::true_type{});
   }
-  tile_loop(ctx_tiles, ctx_tiles + n1, INTERIOR, std::false_type{});
-  tile_loop(ctx_tiles + n1, ctx_tiles + n2, MASKED_, std::false_type{});
-  tile_loop(ctx_tiles + n2, ntiles, SKIP, std::false_type{});
+  if constexpr (PREFIX) {
+    tile_loop(ctx_tiles, ctx_tiles + n1, INTERIOR, std::false_type{});
+    tile_loop(ctx_tiles + n1, ctx_tiles + n2, MASKED_, std::false_type{});
+    tile_loop(ctx_tiles + n2, ntiles, SKIP, std::false_type{});
+  } else {
+    // sliding window: tiles wholly left of every row's window are skipped (64 t + 63 <= w_lo - window), tiles that
+    // some row sees only in part (64 t <= w_hi - window) are masked
+    const int e2 = max(n2, t_start);
+    const int l0 = (window > 0 && w_rows) ? max(w_lo - window + 1, 0) / BN : 0;
+    const int l1 = (window > 0 && w_rows && w_hi >= window) ? (w_hi - window) / BN + 1 : 0;
+    const int b0 = min(max(l0, t_start), e2), b1 = min(max(l1, b0), e2), b2 = min(max(n1, b1), e2);
+    tile_loop(t_start, b0, SKIP, std::false_type{});
+    tile_loop(b0, b1, MASKED_, std::false_type{});
+    tile_loop(b1, b2, INTERIOR, std::false_type{});
+    tile_loop(b2, e2, MASKED_, std::false_type{});
+    tile_loop(e2, ntiles, SKIP, std::false_type{});
+  }
 
 #ifdef VA_PROBES
   if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 2048) {
