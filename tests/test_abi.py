@@ -172,7 +172,7 @@ def test_validation_errors_of_the_neighbour_ops():
             heads * head_size, head_size, kvh * head_size * block_size, head_size * block_size,
             kvh * head_size * block_size, head_size * block_size, 0.1, 0, 0, 0, dtype, kv, None)
     assert pf(batch=0) == 0
-    assert "unsupported head size: 256" in _err(pf(head_size=256))
+    assert "unsupported head size: 264" in _err(pf(head_size=264))
     assert "unsupported head size: 24" in _err(pf(head_size=24, kv=_lib.KV_FP8_E4M3, qs=192))
     assert "unsupported block size: 8" in _err(pf(block_size=8))
     assert "float16, bfloat16 or float32" in _err(pf(dtype=7))
