@@ -428,3 +428,16 @@ def test_unified_fa_kernel_window(oracle, force_fa, window, heads, fp8):
     c = make_unified_case([(700, 700), (300, 1500), (64, 64), (1, 900), (130, 131)], heads[0], heads[1], 128, 16,
                           torch.bfloat16, fp8=fp8, seed=window + heads[0], kv_scale=0.5)
     run(oracle, c, torch.bfloat16, fp8=fp8, window=window)
+
+
+@pytest.mark.parametrize("D", [72, 80, 96, 112, 120])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_unified_fa_kernel_head_sizes(oracle, force_fa, D, fp8, dtype):
+    """Head sizes 72 .. 120 run the 256-row kernel padded to 128 (zero columns from clamped addresses, the last
+    sequence ending at the end of the cache allocation)."""
+    if fp8 and D % 16:
+        pytest.skip("an fp8 cache needs head sizes that are multiples of 16")
+    c = make_unified_case([(300, 700), (1, 90), (70, 70)], 8, 2, D, 16, dtype, fp8=fp8, seed=D, kv_scale=0.5)
+    run(oracle, c, dtype, fp8=fp8)
+    run(oracle, c, dtype, fp8=fp8, window=50)

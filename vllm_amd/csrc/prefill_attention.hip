@@ -815,14 +815,14 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
   // fills at least one of its row blocks.
   {
     const int pack = (gqa > 1 && gqa <= 16) ? gqa : 1;
-    const bool can = head_size == 128 && p.alibi_slopes == nullptr && p.softcap == 0.f &&
+    const bool can = head_size > 64 && head_size <= 128 && p.alibi_slopes == nullptr && p.softcap == 0.f &&
                      p.flat_batch > 0 && p.sm_scale > 0.f && g_pf_rows == 0;
     if (can && g_pf_fa != 1 && (g_pf_fa == 2 || max_q >= 256 / pack)) {
       FaParams f;
       f.o = p.o; f.q = p.q; f.k_cache = p.k_cache; f.v_cache = p.v_cache;
       f.block_table = p.b_loc; f.cu_seqlens_q = p.b_start_loc; f.seq_lens = p.b_seq_len;
       f.k_scale = p.k_scale; f.v_scale = p.v_scale; f.out_scale = p.fp8_out_scale;
-      f.num_heads = p.num_heads; f.num_kv_heads = p.num_kv_heads; f.num_seqs = batch; f.num_tokens = num_tokens;
+      f.head_size = head_size; f.num_heads = p.num_heads; f.num_kv_heads = p.num_kv_heads; f.num_seqs = batch; f.num_tokens = num_tokens;
       f.bs_shift = p.bs_shift; f.skip_decode = p.skip_decode; f.pack = pack;
       f.bt_stride = p.b_loc_stride; f.q_stride_t = p.q_stride_t; f.q_stride_h = p.q_stride_h;
       f.o_stride_t = p.o_stride_t; f.o_stride_h = p.o_stride_h;
@@ -889,14 +889,14 @@ static void launch_d(const PrefillParams& p, int head_size, int block_size, int 
   {
     const int gqa = p.num_heads / p.num_kv_heads;
     const int pack = (gqa > 1 && gqa <= 16) ? gqa : 1;
-    const bool can = head_size == 128 && p.alibi_slopes == nullptr && p.sliding_window == 0 && p.sm_scale > 0.f &&
+    const bool can = head_size > 64 && head_size <= 128 && p.alibi_slopes == nullptr && p.sliding_window == 0 && p.sm_scale > 0.f &&
                      g_pf_rows == 0 && (block_size & (block_size - 1)) == 0;
     if (can && g_pf_fa != 1 && (g_pf_fa == 2 || max_input_len >= 256 / pack)) {
       FaParams f;
       f.o = p.o; f.q = p.q; f.k_cache = p.k_cache; f.v_cache = p.v_cache;
       f.block_table = p.b_loc; f.cu_seqlens_q = p.b_start_loc; f.seq_lens = p.b_seq_len;
       f.k_scale = p.k_scale; f.v_scale = p.v_scale; f.out_scale = p.fp8_out_scale;
-      f.num_heads = p.num_heads; f.num_kv_heads = p.num_kv_heads; f.num_seqs = batch; f.num_tokens = p.flat_tokens;
+      f.head_size = head_size; f.num_heads = p.num_heads; f.num_kv_heads = p.num_kv_heads; f.num_seqs = batch; f.num_tokens = p.flat_tokens;
       f.bs_shift = 0;
       while ((1 << f.bs_shift) < block_size) ++f.bs_shift;
       f.skip_decode = p.skip_decode; f.pack = pack;

@@ -12,6 +12,7 @@ struct FaParams {
   const float* k_scale; const float* v_scale;             // fp8 cache only
   const float* out_scale;                                  // != null: e4m3 output
   int num_heads, num_kv_heads, num_seqs, num_tokens;
+  int head_size;       // 72 .. 128 (padded to 128 inside the kernel)
   int bs_shift;        // log2(block size)
   int skip_decode;     // sequences of query length 1 were taken by the decode kernel
   int pack;            // q heads per tile-row group: the GQA group (rows = (token, head) pairs) or 1

@@ -159,6 +159,9 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   if (p.skip_decode && qlen == 1) return;
   const int new_end = min(tok_base + tpb, qlen);
   const int kvh = pack > 1 ? y : y / (p.num_heads / p.num_kv_heads);
+  // head sizes 72 .. 128 (multiples of 8; 16 with an fp8 cache) run padded to 128: the columns d >= dr of Q, K and V are
+  // staged as zeros from clamped addresses, the output columns are not stored
+  const int dr = p.head_size;
 
   // ---- this lane's query row: tile row 32 wave + l32 -> (token, head) ----------------------------------------
   const int mloc = 32 * wave + l32;
@@ -175,8 +178,9 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
     const T* qp = (const T*)p.q + (int64_t)(tok0 + (rok ? rtok : 0)) * p.q_stride_t + (int64_t)(rok ? rhead : 0) * p.q_stride_h;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(qp + 16 * ks + 8 * hi);
-      qf[ks] = rok ? v : (u32x4){0, 0, 0, 0};
+      const bool dok = 16 * ks + 8 * hi < dr;   // head sizes below 128: zero columns
+      const u32x4 v = *reinterpret_cast<const u32x4*>(qp + (dok ? 16 * ks + 8 * hi : 0));
+      qf[ks] = (rok && dok) ? v : (u32x4){0, 0, 0, 0};
     }
   }
   // wave-uniform: the tokens of the wave's rows
@@ -200,6 +204,8 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
 
   // ---- staging: thread -> (key = tid >> 3, 32 bytes of 16-bit values = LDS chunks 2 piece, 2 piece + 1) -------
   const int skey = tid >> 3, spiece = tid & 7;
+  const bool pv0 = 16 * spiece < dr, pv1 = 16 * spiece + 8 < dr;   // the thread's two 8-column chunks exist
+  const int spl = pv0 ? spiece : 0, o1 = pv1 ? 8 : 0;              // clamped piece / second chunk (16-bit elements)
   constexpr int NST = (FP8 && !PREFIX) ? 1 : 2;
   u32x4 kst[NST], vst[NST];
   // PREFIX, context V^T: thread -> (d = tid & 127, tokens 16 vq .. of the tile)
@@ -225,33 +231,33 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
         const int slot = (t * BN + skey) & bsm;
         const uint8_t* kb = p.k_cache + (int64_t)blk.k * p.kc_block_bytes + (int64_t)kvh * p.kc_head_bytes;
         if constexpr (FP8) {
-          kst[0] = ld16(kb + (((spiece << p.bs_shift) + slot) << 4));
+          kst[0] = ld16(kb + (((spl << p.bs_shift) + slot) << 4));
         } else {
-          kst[0] = ld16(kb + ((((2 * spiece) << p.bs_shift) + slot) << 4));
-          kst[1] = ld16(kb + ((((2 * spiece + 1) << p.bs_shift) + slot) << 4));
+          kst[0] = ld16(kb + ((((2 * spl) << p.bs_shift) + slot) << 4));
+          kst[1] = ld16(kb + ((((2 * spl + (pv1 ? 1 : 0)) << p.bs_shift) + slot) << 4));
         }
         const int slot0 = (t * BN + 16 * vq) & bsm;
         const uint8_t* vb = p.v_cache + (int64_t)blk.v * p.vc_block_bytes + (int64_t)kvh * p.vc_head_bytes +
-                            ((vd << p.bs_shift) + slot0) * (FP8 ? 1 : 2);
+                            ((min(vd, dr - 1) << p.bs_shift) + slot0) * (FP8 ? 1 : 2);
         vst[0] = ld16(vb);
         if constexpr (!FP8) vst[1] = ld16(vb + 16);
       } else {
         const int64_t row = tok0 + min((t - ctx_tiles) * BN + skey, qlen - 1);
-        const T* kr = (const T*)p.k_new + row * p.k_stride_t + (int64_t)kvh * p.k_stride_h + 16 * spiece;
-        const T* vr = (const T*)p.v_new + row * p.v_stride_t + (int64_t)kvh * p.v_stride_h + 16 * spiece;
-        kst[0] = ld16(kr); kst[1] = ld16(kr + 8);
-        vst[0] = ld16(vr); vst[1] = ld16(vr + 8);
+        const T* kr = (const T*)p.k_new + row * p.k_stride_t + (int64_t)kvh * p.k_stride_h + 16 * spl;
+        const T* vr = (const T*)p.v_new + row * p.v_stride_t + (int64_t)kvh * p.v_stride_h + 16 * spl;
+        kst[0] = ld16(kr); kst[1] = ld16(kr + o1);
+        vst[0] = ld16(vr); vst[1] = ld16(vr + o1);
       }
     } else {
       const int slot = (t * BN + skey) & ((1 << p.bs_shift) - 1);
       const uint8_t* kr = p.k_cache + (int64_t)blk.k * p.kc_block_bytes + (int64_t)slot * p.kc_slot_bytes +
-                          (int64_t)kvh * p.kc_head_bytes + 16 * NST * spiece;
+                          (int64_t)kvh * p.kc_head_bytes + 16 * NST * spl;
       const uint8_t* vr = p.v_cache + (int64_t)blk.k * p.vc_block_bytes + (int64_t)slot * p.vc_slot_bytes +
-                          (int64_t)kvh * p.vc_head_bytes + 16 * NST * spiece;
+                          (int64_t)kvh * p.vc_head_bytes + 16 * NST * spl;
 #pragma unroll
       for (int i = 0; i < NST; ++i) {
-        kst[i] = ld16(kr + 16 * i);
-        vst[i] = ld16(vr + 16 * i);
+        kst[i] = ld16(kr + (i ? 2 * o1 : 0));   // (fp8: one load; 16-bit: the second chunk 16 bytes on, if it exists)
+        vst[i] = ld16(vr + (i ? 2 * o1 : 0));
       }
     }
   };
@@ -280,12 +286,13 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
     } else {
       k0 = kst[0]; k1 = kst[NST - 1];
     }
-    if (!live) { k0 = (u32x4){0, 0, 0, 0}; k1 = k0; }
+    if (!live || !pv0) k0 = (u32x4){0, 0, 0, 0};
+    if (!live || !pv1) k1 = (u32x4){0, 0, 0, 0};
     *reinterpret_cast<u32x4*>(k_wr + kb_ + kc0) = k0;
     *reinterpret_cast<u32x4*>(k_wr + kb_ + kc1) = k1;
     if (is_ctx) {
       // V^T: the thread's 16 tokens of row vd = four 8-byte units
-      const int valid = ctx - (t * BN + 16 * vq);
+      const int valid = vd < dr ? ctx - (t * BN + 16 * vq) : 0;
       uint4 lo, hi4;
       if constexpr (FP8) {
         widen16<T>(mask_bytes(u4(vst[0]), valid), lo, hi4);
@@ -308,7 +315,8 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
       } else {
         v0 = vst[0]; v1 = vst[NST - 1];
       }
-      if (!live) { v0 = (u32x4){0, 0, 0, 0}; v1 = v0; }
+      if (!live || !pv0) v0 = (u32x4){0, 0, 0, 0};
+      if (!live || !pv1) v1 = (u32x4){0, 0, 0, 0};
       *reinterpret_cast<u32x4*>(v_wr + vb_ + vc0) = v0;
       *reinterpret_cast<u32x4*>(v_wr + vb_ + vc1) = v1;
     }
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
       for (int rq = 0; rq < 4; ++rq) {
         const u32x2 w = {Mma<T>::pack2(o[db][4 * rq] * inv, o[db][4 * rq + 1] * inv),
                          Mma<T>::pack2(o[db][4 * rq + 2] * inv, o[db][4 * rq + 3] * inv)};
-        *reinterpret_cast<u32x2*>(op + 32 * db + 8 * rq) = w;
+        if (32 * db + 8 * rq + 4 * hi < dr) *reinterpret_cast<u32x2*>(op + 32 * db + 8 * rq) = w;
       }
   } else {
     const float oinv = inv / *p.out_scale;   // acc / l / out_scale, clamped to the e4m3 range (:282-287)
@@ -570,7 +578,8 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
         float yv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) yv[r] = fmaxf(-448.0f, fminf(o[db][4 * rq + r] * oinv, 448.0f));
-        *reinterpret_cast<uint32_t*>(op + 32 * db + 8 * rq) = f32x4_to_fp8x4(yv[0], yv[1], yv[2], yv[3]);
+        if (32 * db + 8 * rq + 4 * hi < dr)
+          *reinterpret_cast<uint32_t*>(op + 32 * db + 8 * rq) = f32x4_to_fp8x4(yv[0], yv[1], yv[2], yv[3]);
       }
   }
 }
