@@ -482,7 +482,9 @@ int vllm_amd_ar_free_shared(void* ptr);
 /*                 17 = 256x256 on 16 waves; 18..25 = scaled_mm_pp.hip (value - 18:   */
 /*                 bit 0 stagger, bit 1 persistent, bit 2 stagger by a quarter     */
 /*                 block; 21 = what the heuristic ships for MFMA-bound shapes),     */
-/*                 26..28 = 64x64 / 128x64 tiles with deeper rings (no gain)        */
+/*                 26..28 = 64x64 / 128x64 tiles with deeper rings (no gain),       */
+/*                 29..36 = 18..25 with 256 x 192 tiles (the heuristic takes them  */
+/*                 where they save a round of workgroups: N 6144)                  */
 /*   "mm_patch":   tile columns per super-column of the scaled_mm_pp tile order    */
 /*                 (default 8; <= 1 = column-major)                                  */
 /*   "mm_store":   scaled_mm_pp measurement: 3 = no output stores (garbage)         */

@@ -143,7 +143,8 @@ def test_scaled_mm_configs2_large_m_sampled_oracle(ops, oracle, KN, M):
 
 @pytest.mark.parametrize("MNK", [(4096, 4096, 1024), (1000, 1288, 1024), (2304, 2816, 512), (4096, 10240, 384)])
 def test_scaled_mm_pp_variants_identical(ops, MNK):
-    """The staggered / persistent forms of the 256 x 256 kernel (scaled_mm_pp.hip, "mm_kernel" 18-25) keep
+    """The staggered / persistent forms of the 256 x 256 kernel (scaled_mm_pp.hip, "mm_kernel" 18-25; 29-36: the same
+    with 256 x 192 tiles) keep
     the K order and the MFMA of the kernel of scaled_mm_large.hip ("mm_kernel" 2): bit-identical outputs on
     random operands, with bias, ragged edges, one and several tiles per workgroup."""
     from vllm_amd import _lib
@@ -152,7 +153,7 @@ def test_scaled_mm_pp_variants_identical(ops, MNK):
     a, w, sa, sb, b = a.cuda(), w.cuda(), sa.cuda(), sb.cuda(), b.cuda()
     try:
         outs = {}
-        for k in (2, 18, 19, 20, 21, 23, 25, 0):
+        for k in (2, 18, 19, 20, 21, 23, 25, 29, 30, 31, 32, 34, 36, 0):
             _lib.set_tuning("mm_kernel", k)
             outs[k] = ops.cutlass_scaled_mm(a, w.t(), sa, sb, torch.bfloat16, b)
     finally:
@@ -174,7 +175,7 @@ def force_kernel():
     _lib.set_tuning("mm_splitk", 0)
 
 
-@pytest.mark.parametrize("kernel", list(range(1, 29)))
+@pytest.mark.parametrize("kernel", list(range(1, 37)))
 @pytest.mark.parametrize("MNK", [(300, 520, 256), (256, 256, 1024), (257, 971, 384), (640, 1288, 2048),
                                  (40, 8, 128 * 3), (5, 264, 512), (32, 1040, 1024)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])

@@ -331,19 +331,20 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
     int sel = g_mm_kernel;
     const int want_splits = req_splits > 0 ? req_splits : g_mm_splitk;   // 0 = heuristic
     int splits = want_splits > 0 ? want_splits : 1;
-    if (sel >= 18 && sel <= 25) {
+    if (sel >= 29 && sel <= 36) sel = -(sel - 29 + 8) - 100;   // 29 .. 36: the same variants with 256 x 192 tiles
+    if ((sel >= 18 && sel <= 25) || sel <= -100) {
       // the staggered / persistent 256 x 256 kernel (scaled_mm_pp.hip), forced: 18 plain, 19 stagger,
       // 20 persistent, 21 both
       const bool vec16 = ldc % 8 == 0 && N % 8 == 0 && ((((uintptr_t)out) & 15) == 0);
       if (vec16) {
-        launch_scaled_mm_pp(sel - 18, out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc,
-                            a_scale_numel, b_scale_numel, out_dtype, st);
+        launch_scaled_mm_pp(sel <= -100 ? -(sel + 100) : sel - 18, out, a, b, a_scales, b_scales, bias, M, N, K, lda,
+                            ldb, ldc, a_scale_numel, b_scale_numel, out_dtype, st);
         VA_LAUNCH_CHECK(op);
         return VLLM_AMD_OK;
       }
       sel = 2;
     }
-    if (sel == 0 || sel == 11 || sel > 28) {
+    if (sel == 0 || sel == 11 || sel > 36) {
       // Largest tile that still yields ~3/4 of a full wave of workgroups (256 CUs); rows of
       // a tile beyond M are wasted MFMA work, so BM <= 2 M.  With more than one wave of tiles the
       // variant that fits several workgroups per CU wins, below that the variant that takes
@@ -386,7 +387,14 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
       // N 6144 100 (92.7 with the tail split below) -> 85.1: profiles/r03_gemm_pp.txt).  It writes 16-byte
       // pieces of rows, so outputs that do not allow them keep the kernel of scaled_mm_large.hip.
       if (sel == 2 && g_mm_kernel == 0 && splits == 1 && vec16) {
-        launch_scaled_mm_pp(3, out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc,
+        // 256 x 192 tiles where they save a round of workgroups: a 192-wide tile costs ~7/8 of a 256-wide one (it
+        // stages 56 instead of 64 KiB per K block), so N 6144 (the fused qkv projection) at M 3072 -- 288 tiles = 2
+        // rounds against 384 narrow ones = 2 x 7/8 -- goes 90.2 -> 78.9 us, at M 4096 / 2048 91.5 / 52.3 -> 89.2 /
+        // 50.7 us; everywhere else on the benchmark grid the wide tile has fewer or equal rounds (profiles/r03_gemm_pp.txt 13)
+        const int tm = ceil_div(M, 256);
+        const int r256 = ceil_div(tm * ceil_div(N, 256), 256), r192 = ceil_div(tm * ceil_div(N, 192), 256);
+        const int variant = (8 * r256 > 7 * r192) ? (3 | 8) : 3;
+        launch_scaled_mm_pp(variant, out, a, b, a_scales, b_scales, bias, M, N, K, lda, ldb, ldc,
                             a_scale_numel, b_scale_numel, out_dtype, st);
         VA_LAUNCH_CHECK(op);
         return VLLM_AMD_OK;

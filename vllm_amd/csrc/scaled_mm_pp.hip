@@ -32,13 +32,11 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int LBK = 128;                 // K block in bytes = one MFMA
-constexpr int BM = 256, BN = 256;
-constexpr int NW = 8, WN = 4;            // waves as 2 (m) x 4 (n): 128 x 64 outputs per wave
-constexpr int MT = 8, NT = 4;            // MFMA tiles per wave
-constexpr int A_BYTES = BM * LBK, W_BYTES = BN * LBK, STAGE = A_BYTES + W_BYTES;
-constexpr int EPI_OFF = 2 * STAGE, EPI_WAVE = 4096;
-constexpr int LDS_TOTAL = EPI_OFF + NW * EPI_WAVE;   // 160 KiB
-constexpr int ROUNDS = BM / (8 * NW);    // 4 LDS-DMA rounds per operand and wave
+constexpr int BM = 256;
+constexpr int NW = 8, WN = 4;            // waves as 2 (m) x 4 (n): 128 x 16 NT outputs per wave
+constexpr int MT = 8;                    // MFMA tiles per wave along m; along n: the template's NT (4, or 3 = 256 x 192 tiles)
+constexpr int A_BYTES = BM * LBK, EPI_WAVE = 4096;
+constexpr int ROUNDS = BM / (8 * NW);    // 4 LDS-DMA rounds per wave for the activation rows (NT for the weight rows)
 
 // -DVA_PROBES (tools/pp_stamps.py): 100 MHz time stamps per wave, stored as they are taken: 0 kernel
 // entry, 1 exit of the first barrier, 2 end of the K loop, 3 epilogue stores issued, 4 stores done;
@@ -87,12 +85,17 @@ __device__ __forceinline__ i32x8 cat8(i32x4 lo, i32x4 hi) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <typename out_t, bool STAGGER, int DEFER>
+template <typename out_t, bool STAGGER, int DEFER, int NT>
 __global__ __launch_bounds__(64 * NW) void scaled_mm_pp_kernel(
     out_t* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ a_scales, const float* __restrict__ b_scales,
     const out_t* __restrict__ bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
     int a_scale_numel, int b_scale_numel, int persistent, int pw, int store_mode, int prio) {
+  // tile = 256 x 64 NT: 256 x 256, or 256 x 192 for outputs whose 256-wide tiles leave the last round of workgroups
+  // half empty (N 6144 at M 4096: 384 tiles = 2 rounds of 256 workgroups, 512 tiles of 192 columns = 2 rounds of 3/4 the work)
+  constexpr int BN = 64 * NT, W_BYTES = BN * LBK, STAGE = A_BYTES + W_BYTES;
+  constexpr int EPI_OFF = 2 * STAGE, LDS_TOTAL = EPI_OFF + NW * EPI_WAVE;   // 160 KiB (NT 4), 144 KiB (NT 3)
+  constexpr int WROUNDS = BN / (8 * NW);
   __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TOTAL];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(64 * NW) void scaled_mm_pp_kernel(
   // ---- staging: in round r wave w fills rows [64 r + 8 w, +8): lane -> (row = lane >> 3, slot = lane & 7)
   // and loads logical chunk slot ^ f(row), so that the lane-linear LDS image is the swizzled tile
   const int srow = lane >> 3, sslot = lane & 7;
-  uint32_t a_voff[ROUNDS], w_voff[ROUNDS];   // of the tile whose blocks are being LOADED
+  uint32_t a_voff[ROUNDS], w_voff[WROUNDS];   // of the tile whose blocks are being LOADED
   auto set_load_tile = [&](int id) __attribute__((always_inline)) {
     int tm, tn;
     tile_mn(id, tm, tn);
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(64 * NW) void scaled_mm_pp_kernel(
       const uint32_t sw = (uint32_t)((sslot ^ lswz(row)) << 4);
       const int m = min(m0 + row, M - 1), n = min(n0 + row, N - 1);   // rows past the end: any valid row
       a_voff[r] = (uint32_t)m * (uint32_t)lda + sw;
-      w_voff[r] = (uint32_t)n * (uint32_t)ldb + sw;
+      if (r < WROUNDS) w_voff[r] = (uint32_t)n * (uint32_t)ldb + sw;
     }
   };
   auto stage_load = [&](int stage, int k0) __attribute__((always_inline)) {
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(64 * NW) void scaled_mm_pp_kernel(
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a + k0 + a_voff[r]),
                                        (__attribute__((address_space(3))) void*)(base + 64 * r * LBK), 16, 0, 0);
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r)
+    for (int r = 0; r < WROUNDS; ++r)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + k0 + w_voff[r]),
                                        (__attribute__((address_space(3))) void*)(base + A_BYTES + 64 * r * LBK), 16, 0, 0);
   };
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(64 * NW) void scaled_mm_pp_kernel(
     uint8_t* mine = lds + EPI_OFF + wave * EPI_WAVE;
     const int rrow = lane >> 3, rch = lane & 7;   // read-back: row within 8, 16-byte chunk
     // store address of (row rrow, chunk rch) of sub-tile 0; a row down = ldc8 16-byte units
-    const bool ncol_ok = n0 + 8 * rch < N && store_mode != 3;
+    const bool ncol_ok = n0 + 8 * rch < N && rch < 2 * NT && store_mode != 3;
     u32x4* orow = reinterpret_cast<u32x4*>(out + (int64_t)(m0 + rrow) * ldc + n0 + 8 * rch);
     const int64_t ldc8 = ldc / 8;   // host: ldc % 8 == 0
     // software pipeline over the m-steps: sub-tile mt is written to buffer mt & 1 while sub-tile mt - 1 is
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(64 * NW) void scaled_mm_pp_kernel(
       read_frag<0>(aa0, aa1, al[0], ah[0]);
       read_frag<1>(wa0, wa1, wl[1], wh[1]);
       read_frag<2>(wa0, wa1, wl[2], wh[2]);
-      read_frag<3>(wa0, wa1, wl[3], wh[3]);
+      if constexpr (NT > 3) read_frag<3>(wa0, wa1, wl[3], wh[3]);
       if (pending < 0) {
         if (!more_k && more) set_load_tile(id + stride);
         if (more) stage_load((gb & 1) ^ 1, nk0);
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(64 * NW) void scaled_mm_pp_kernel(
         // reads younger than A(mt): A(mt+1) and D(mt) of this step, D(mt-1) of the one before
         constexpr int later = (nxt ? 2 : 0) + (dnow ? 2 : 0) + (dprev ? 2 : 0);
         if constexpr (mt == 0) {
-          wait4<later + 6>(wl[0], wh[0], al[0], ah[0]);
+          wait4<later + 2 * (NT - 1)>(wl[0], wh[0], al[0], ah[0]);
           const i32x8 af = cat8(al[0], ah[0]);
           wf[0] = cat8(wl[0], wh[0]);
           acc[0][0] = mfma(wf[0], af, acc[0][0]);
@@ -398,13 +401,19 @@ int g_mm_patch = 8;   // tuning "mm_patch": tile columns per super-column of the
 int launch_scaled_mm_pp(int variant, void* out, const void* a, const void* b, const float* a_scales,
                         const float* b_scales, const void* bias, int M, int N, int K, int64_t lda,
                         int64_t ldb, int64_t ldc, int asn, int bsn, int out_dtype, hipStream_t st) {
-  const int T = ceil_div(M, pp::BM) * ceil_div(N, pp::BN);
+  // variant bit 3: 256 x 192 tiles
+  const bool narrow = (variant & 8) != 0;
+  const int T = ceil_div(M, pp::BM) * ceil_div(N, narrow ? 192 : 256);
   const bool persistent = (variant & 2) && T > 256;
   const int grid = persistent ? 256 : T;
-#define PP_LAUNCH(T_, STG, DFR)                                                                         \
-  hipLaunchKernelGGL((pp::scaled_mm_pp_kernel<T_, STG, DFR>), dim3(grid), dim3(64 * pp::NW), 0, st,      \
+#define PP_LAUNCH_(T_, STG, DFR, NT_)                                                                    \
+  hipLaunchKernelGGL((pp::scaled_mm_pp_kernel<T_, STG, DFR, NT_>), dim3(grid), dim3(64 * pp::NW), 0, st,  \
                      (T_*)out, (const uint8_t*)a, (const uint8_t*)b, a_scales, b_scales,            \
                      (const T_*)bias, M, N, K, lda, ldb, ldc, asn, bsn, persistent ? 1 : 0, g_mm_patch, g_mm_store, g_mm_prio)
+#define PP_LAUNCH(T_, STG, DFR)                                                  \
+  do {                                                                           \
+    if (narrow) PP_LAUNCH_(T_, STG, DFR, 3); else PP_LAUNCH_(T_, STG, DFR, 4);   \
+  } while (0)
   if (out_dtype == VLLM_AMD_BF16) {
     if ((variant & 5) == 5) PP_LAUNCH(bf16_t, true, 2); else if (variant & 1) PP_LAUNCH(bf16_t, true, 4);
     else PP_LAUNCH(bf16_t, false, 4);
@@ -412,6 +421,7 @@ int launch_scaled_mm_pp(int variant, void* out, const void* a, const void* b, co
     if ((variant & 5) == 5) PP_LAUNCH(f16_t, true, 2); else if (variant & 1) PP_LAUNCH(f16_t, true, 4);
     else PP_LAUNCH(f16_t, false, 4);
   }
+#undef PP_LAUNCH_
 #undef PP_LAUNCH
   return VLLM_AMD_OK;
 }
