@@ -1,5 +1,6 @@
-// unified_attention (vllm/attention/ops/triton_unified_attention.py:52-272, 588-700) for LONG query chunks at
-// head size 128 with nothing but the causal + padding mask: the matrix-core-bound case of prefill_attention.hip,
+// unified_attention (vllm/attention/ops/triton_unified_attention.py:52-272, 588-700) and context_attention_fwd
+// (vllm/attention/ops/prefix_prefill.py:36-288, 726-913; the PREFIX instantiation below) for LONG query chunks at head
+// sizes 72 .. 128 with the causal + padding mask (unified: + sliding window): the matrix-core-bound case of prefill_attention.hip,
 // re-built around what bounds that kernel (16 query rows per wave = one LDS fragment byte per
 // 32 flops and ~300 VALU per 32 MFMAs; a 64-row tile restages every K / V tile for 64 rows).
 //
@@ -14,9 +15,10 @@
 //     row max and sum need one cross-half exchange, and the C layout of S^T (keys (r & 3) + 8 (r >> 2) + 4 hi of
 //     a 32-key block) is the B layout of P^T once the contraction slots of the PV product are numbered the
 //     same way -- the V^T fragment is simply read in that order.  P never leaves the registers;
-//   * K / V tiles of 64 keys, double-buffered in LDS, one barrier per tile: the loads of tile t + 2 are issued
-//     (global -> registers) before the PV product of tile t, and written to LDS (fp8 widened exactly on the
-//     way) after the softmax of tile t + 1;
+//   * K / V tiles of 64 keys, double-buffered in LDS (64 KiB), one barrier per tile: registers hold tile t + 1
+//     while tile t is computed; in interval t they are written to the other buffer (fp8 widened exactly on the way)
+//     and the loads of tile t + 2 are issued -- by waves 0-3 behind their compute, by waves 4-7 in front of it, so
+//     that one wave of every SIMD stages while its partner is in its MFMA sections;
 //   * the running max is updated lazily: O and l are rescaled only when some row's tile max exceeds the
 //     running max by more than 2^8 (the probabilities then reach at most 256, exact in the 16-bit formats'
 //     exponent range; every row is normalised by its own sum at the end).
@@ -107,7 +109,7 @@ __device__ unsigned long long g_fa_stamps[2048 * 8 * 8];
 // tokens take the unified path's row-major image and transposing reads.  Dense k / v are never fp8.
 template <typename T, bool FP8, bool PREFIX>
 __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[(KN + VN) * TILE];   // 96 KiB
+  __shared__ __attribute__((aligned(16))) uint8_t lds[(KN + VN) * TILE];   // 64 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, hi = lane >> 5;
