@@ -13,6 +13,7 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--unified", action="store_true", help="unified_attention over a flash-layout cache")
 ap.add_argument("--rows", type=int, default=0, help="query rows per workgroup (tuning pf_rows)")
 ap.add_argument("--hnd", action="store_true", help="unified: head-major cache memory (permuted view)")
+ap.add_argument("--shapes", default="4x2048x0,4x2048x2048,1x8192x0,16x512x3584,64x128x4096", help="BxQxCTX,...")
 ap.add_argument("--window", type=int, default=0, help="unified: sliding window (keys)")
 ap.add_argument("--D", type=int, default=128, help="head size")
 ap.add_argument("--set", default="", help="tuning keys: k=v[,k=v]")
@@ -29,7 +30,7 @@ if a.rows:
     from vllm_amd import _lib
     _lib.set_tuning("pf_rows", a.rows)
 H, KVH, D, BS = 32, 8, a.D, 16
-for (B, ql, cl) in ((4, 2048, 0), (4, 2048, 2048), (1, 8192, 0), (16, 512, 3584), (64, 128, 4096)):
+for (B, ql, cl) in [tuple(int(x) for x in sh.split('x')) for sh in a.shapes.split(',')]:
     T = B * ql
     g = torch.Generator(device=dev).manual_seed(0)
     q = (torch.rand((T, H, D), device=dev, generator=g) - 0.5).to(torch.bfloat16)
