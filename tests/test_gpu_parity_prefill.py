@@ -273,14 +273,16 @@ def test_prefill_wide_heads(oracle, head_size, kv, gqa):
     torch.testing.assert_close(out.float(), prefill_reference(c), atol=tol(torch.bfloat16), rtol=0)
 
 
-@pytest.mark.parametrize("head_size", [72, 80, 96, 112, 120])
+@pytest.mark.parametrize("head_size", [72, 80, 96, 112, 120, 136, 160, 192, 224, 256])
 @pytest.mark.parametrize("kv", ["auto", "fp8"])
 def test_prefill_fa_kernel_head_sizes(oracle, force_fa, head_size, kv):
-    """Head sizes 72 .. 120 through the 256-row kernel (padded to 128) on the prefix layout."""
+    """Head sizes 72 .. 120 through the 256-row kernel (padded to 128) on the prefix layout, 136 .. 256 through its
+    four-wave form (padded to 256)."""
     if kv == "fp8" and head_size % 16:
         pytest.skip("an fp8 cache needs head sizes that are multiples of 16")
-    c = make_prefill_case([1, 150, 77, 300], [200, 0, 131, 64], 4, 2, head_size, 16, torch.bfloat16, kv,
-                          seed=head_size, kv_scale=0.02)
-    out = run(c, kv)
-    assert not out.isnan().any()
-    torch.testing.assert_close(out.float(), run_oracle(oracle, c, kv).float(), atol=tol(torch.bfloat16), rtol=0)
+    for bs in (16, 32) if head_size in (96, 256) else (16,):
+        c = make_prefill_case([1, 150, 77, 300], [200, 0, 131, 64], 4, 2, head_size, bs, torch.bfloat16, kv,
+                              seed=head_size, kv_scale=0.02)
+        out = run(c, kv)
+        assert not out.isnan().any()
+        torch.testing.assert_close(out.float(), run_oracle(oracle, c, kv).float(), atol=tol(torch.bfloat16), rtol=0)

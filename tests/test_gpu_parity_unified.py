@@ -430,14 +430,19 @@ def test_unified_fa_kernel_window(oracle, force_fa, window, heads, fp8):
     run(oracle, c, torch.bfloat16, fp8=fp8, window=window)
 
 
-@pytest.mark.parametrize("D", [72, 80, 96, 112, 120])
+@pytest.mark.parametrize("D", [72, 80, 96, 112, 120, 136, 160, 192, 224, 256])
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_unified_fa_kernel_head_sizes(oracle, force_fa, D, fp8, dtype):
     """Head sizes 72 .. 120 run the 256-row kernel padded to 128 (zero columns from clamped addresses, the last
-    sequence ending at the end of the cache allocation)."""
+    sequence ending at the end of the cache allocation), 136 .. 256 its four-wave form padded to 256."""
     if fp8 and D % 16:
         pytest.skip("an fp8 cache needs head sizes that are multiples of 16")
     c = make_unified_case([(300, 700), (1, 90), (70, 70)], 8, 2, D, 16, dtype, fp8=fp8, seed=D, kv_scale=0.5)
     run(oracle, c, dtype, fp8=fp8)
     run(oracle, c, dtype, fp8=fp8, window=50)
+    if D == 256:   # unpacked rows, a group that does not divide the 128 rows, fp8 output
+        c = make_unified_case([(200, 333), (64, 64)], 6, 2, D, 32, dtype, fp8=fp8, seed=1, kv_scale=0.5)
+        run(oracle, c, dtype, fp8=fp8)
+        c = make_unified_case([(200, 333), (64, 64)], 4, 4, D, 16, dtype, fp8=fp8, seed=2, kv_scale=0.5)
+        run(oracle, c, dtype, fp8=fp8, out_scale=torch.tensor([0.03]))

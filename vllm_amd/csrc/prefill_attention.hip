@@ -815,13 +815,14 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
   // fills at least one of its row blocks.
   {
     const int pack = (gqa > 1 && gqa <= 16) ? gqa : 1;
-    const bool can = head_size > 64 && head_size <= 128 && p.alibi_slopes == nullptr && p.softcap == 0.f &&
+    const int fa_rows = head_size > 128 ? 128 : 256;   // rows of a workgroup: four waves at head sizes above 128
+    const bool can = head_size > 64 && head_size <= 256 && p.alibi_slopes == nullptr && p.softcap == 0.f &&
                      p.flat_batch > 0 && p.sm_scale > 0.f && g_pf_rows == 0;
     // ... and the launch has enough 256-row blocks for the chip: below ~128 of them the 64-row kernel's four times as
     // many workgroups finish sooner (chunk 256 over 4096 cached tokens among 255 decodes: 32 blocks, 82 vs 150 us)
     const int64_t ptok = mixed ? (int64_t)num_tokens - batch : (int64_t)num_tokens;   // ~ tokens of the chunks
-    const int64_t fa_blocks = ptok / (256 / pack) * (pack > 1 ? p.num_kv_heads : p.num_heads);
-    if (can && g_pf_fa != 1 && (g_pf_fa == 2 || (max_q >= 256 / pack && fa_blocks >= 128))) {
+    const int64_t fa_blocks = ptok / (fa_rows / pack) * (pack > 1 ? p.num_kv_heads : p.num_heads);
+    if (can && g_pf_fa != 1 && (g_pf_fa == 2 || (max_q >= fa_rows / pack && fa_blocks >= 128))) {
       FaParams f;
       f.o = p.o; f.q = p.q; f.k_cache = p.k_cache; f.v_cache = p.v_cache;
       f.block_table = p.b_loc; f.cu_seqlens_q = p.b_start_loc; f.seq_lens = p.b_seq_len;
@@ -893,11 +894,12 @@ static void launch_d(const PrefillParams& p, int head_size, int block_size, int 
   {
     const int gqa = p.num_heads / p.num_kv_heads;
     const int pack = (gqa > 1 && gqa <= 16) ? gqa : 1;
-    const bool can = head_size > 64 && head_size <= 128 && p.alibi_slopes == nullptr && p.sliding_window == 0 && p.sm_scale > 0.f &&
+    const int fa_rows = head_size > 128 ? 128 : 256;
+    const bool can = head_size > 64 && head_size <= 256 && p.alibi_slopes == nullptr && p.sliding_window == 0 && p.sm_scale > 0.f &&
                      g_pf_rows == 0 && (block_size & (block_size - 1)) == 0;
     const int64_t ptok = p.flat_batch > 0 ? (int64_t)p.flat_tokens : (int64_t)max_input_len * batch;
-    const int64_t fa_blocks = ptok / (256 / pack) * (pack > 1 ? p.num_kv_heads : p.num_heads);   // (see launch_unified)
-    if (can && g_pf_fa != 1 && (g_pf_fa == 2 || (max_input_len >= 256 / pack && fa_blocks >= 128))) {
+    const int64_t fa_blocks = ptok / (fa_rows / pack) * (pack > 1 ? p.num_kv_heads : p.num_heads);   // (see launch_unified)
+    if (can && g_pf_fa != 1 && (g_pf_fa == 2 || (max_input_len >= fa_rows / pack && fa_blocks >= 128))) {
       FaParams f;
       f.o = p.o; f.q = p.q; f.k_cache = p.k_cache; f.v_cache = p.v_cache;
       f.block_table = p.b_loc; f.cu_seqlens_q = p.b_start_loc; f.seq_lens = p.b_seq_len;
@@ -914,7 +916,7 @@ static void launch_d(const PrefillParams& p, int head_size, int block_size, int 
       f.window = 0;
       f.prefix = 1; f.k_new = p.k; f.v_new = p.v;
       f.k_stride_t = p.k_stride_t; f.k_stride_h = p.k_stride_h; f.v_stride_t = p.v_stride_t; f.v_stride_h = p.v_stride_h;
-      const int tpb = 256 / pack;
+      const int tpb = fa_rows / pack;
       f.blocks_per_seq = p.flat_batch > 0 ? 0 : (max_input_len + tpb - 1) / tpb;
       f.abl = 0; f.stagger = g_pf_fa_stagger;
       launch_unified_fa(f, std::is_same<T, f16_t>::value ? VLLM_AMD_F16 : VLLM_AMD_BF16, FP8, st);

@@ -52,12 +52,9 @@ template <> struct Mma32<f16_t> {
   }
 };
 
-constexpr int BM = 256, BN = 64, D = 128, NW = 8;
-constexpr int ROWB = 2 * D;       // bytes per LDS row (one key, 128 16-bit values)
-constexpr int TILE = BN * ROWB;   // 16 KiB
+constexpr int BN = 64;            // keys per tile
 constexpr int KN = 2, VN = 2;     // K / V tiles in LDS (rings indexed by the tile number)
 constexpr int KR = 8, VR = 4;     // fragment reads in flight: K reads, V^T fragments (two transposing reads each)
-constexpr int K_OFF = 0, V_OFF = KN * TILE;
 constexpr float THR = 8.f;        // lazy rescale threshold (log2 domain)
 
 __device__ __forceinline__ float max3(float a, float b, float c) {
@@ -107,9 +104,21 @@ __device__ unsigned long long g_fa_stamps[2048 * 8 * 8];
 // visible -- followed by the new tokens' dense k / v (causal).  Context V is already V^T: its tile is staged as
 // [d][token] (8-byte units XOR-swizzled by d >> 1) and the PV MFMA's A operand is two plain 8-byte reads; the new
 // tokens take the unified path's row-major image and transposing reads.  Dense k / v are never fp8.
-template <typename T, bool FP8, bool PREFIX>
-__global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[(KN + VN) * TILE];   // 64 KiB
+//
+// D_ = 128, NW_ = 8: head sizes 72 .. 128, eight waves = 256 rows, two waves per SIMD.
+// D_ = 256, NW_ = 4: head sizes 136 .. 256: O^T alone is 128 registers for a wave's 32 rows and Q^T 64, so a wave takes a
+// whole SIMD's register file: four waves = 128 rows, one per SIMD, 32 KiB tiles (128 KiB of LDS), 32 + 32 MFMAs per tile.
+template <typename T, bool FP8, bool PREFIX, int D_, int NW_>
+__global__ __launch_bounds__(64 * NW_) void fa_fwd_kernel(const FaParams p) {
+  constexpr int NW = NW_, BM = 32 * NW, D = D_;
+  constexpr int ROWB = 2 * D;       // bytes per LDS row (one key, D 16-bit values)
+  constexpr int TILE = BN * ROWB;   // 16 / 32 KiB
+  constexpr int K_OFF = 0, V_OFF = KN * TILE;
+  constexpr int KS = D / 16, DB = D / 32;         // k-steps of S^T, d blocks of O^T
+  constexpr int PPK = D / 16;                     // 32-byte staging pieces per key
+  constexpr int NTHR = 64 * NW, IPT = BN * PPK / NTHR, KSTEP = NTHR / PPK;   // staging items per thread, keys between them
+  static_assert(IPT * NTHR == BN * PPK && (IPT == 1 || KSTEP % 16 == 0) && 4 * D == IPT * NTHR, "");
+  __shared__ __attribute__((aligned(16))) uint8_t lds[(KN + VN) * TILE];   // 64 / 128 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, hi = lane >> 5;
@@ -175,11 +184,11 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   const int bound_new = rok ? (PREFIX ? rtok : ctx + rtok) : -1;
   const int bound_ctx = rok ? ctx - 1 : -1;
   // Q^T fragments (B operand of S^T): column m = this row, k = d = 16 ks + 8 hi + (0..7)
-  u32x4 qf[8];
+  u32x4 qf[KS];
   {
     const T* qp = (const T*)p.q + (int64_t)(tok0 + (rok ? rtok : 0)) * p.q_stride_t + (int64_t)(rok ? rhead : 0) * p.q_stride_h;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const bool dok = 16 * ks + 8 * hi < dr;   // head sizes below 128: zero columns
       const u32x4 v = *reinterpret_cast<const u32x4*>(qp + (dok ? 16 * ks + 8 * hi : 0));
       qf[ks] = (rok && dok) ? v : (u32x4){0, 0, 0, 0};
@@ -204,68 +213,79 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   const int* bt = p.block_table + (int64_t)seq * p.bt_stride;
   const int last_page = PREFIX ? (ctx > 0 ? (ctx - 1) >> p.bs_shift : 0) : (seq_len - 1) >> p.bs_shift;
 
-  // ---- staging: thread -> (key = tid >> 3, 32 bytes of 16-bit values = LDS chunks 2 piece, 2 piece + 1) -------
-  const int skey = tid >> 3, spiece = tid & 7;
+  // ---- staging: item = tid + NTHR i -> (key = tid / PPK + KSTEP i, 32 bytes of 16-bit values = LDS chunks 2 piece,
+  // 2 piece + 1 with piece = tid % PPK) ----------------------------------------------------------------------------
+  const int skey = tid / PPK, spiece = tid % PPK;
   const bool pv0 = 16 * spiece < dr, pv1 = 16 * spiece + 8 < dr;   // the thread's two 8-column chunks exist
   const int spl = pv0 ? spiece : 0, o1 = pv1 ? 8 : 0;              // clamped piece / second chunk (16-bit elements)
   constexpr int NST = (FP8 && !PREFIX) ? 1 : 2;
-  u32x4 kst[NST], vst[NST];
-  // PREFIX, context V^T: thread -> (d = tid & 127, tokens 16 vq .. of the tile)
-  const int vd = tid & 127, vq = tid >> 7;
-  struct Blk { int k, v; };
+  u32x4 kst[IPT][NST], vst[IPT][NST];
+  // PREFIX, context V^T: item -> (d = item % D, tokens 16 vq .. of the tile with vq = item / D)
+  auto vd_of = [&](int i) __attribute__((always_inline)) { return (tid + NTHR * i) % D; };
+  auto vq_of = [&](int i) __attribute__((always_inline)) { return (tid + NTHR * i) / D; };
+  struct Blk { int k[IPT], v[IPT]; };
   auto load_blk = [&](int t) __attribute__((always_inline)) {
-    Blk b = {0, 0};
-    if constexpr (PREFIX) {
-      if (t < ctx_tiles) {
-        b.k = bt[min((t * BN + skey) >> p.bs_shift, last_page)];
-        b.v = bt[min((t * BN + 16 * vq) >> p.bs_shift, last_page)];
+    Blk b;
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      b.k[i] = 0; b.v[i] = 0;
+      if constexpr (PREFIX) {
+        if (t < ctx_tiles) {
+          b.k[i] = bt[min((t * BN + skey + KSTEP * i) >> p.bs_shift, last_page)];
+          b.v[i] = bt[min((t * BN + 16 * vq_of(i)) >> p.bs_shift, last_page)];
+        }
+      } else {
+        if (t < ntiles) b.k[i] = bt[min((t * BN + skey + KSTEP * i) >> p.bs_shift, last_page)];
       }
-    } else {
-      if (t < ntiles) b.k = bt[min((t * BN + skey) >> p.bs_shift, last_page)];
     }
     return b;
   };
   auto ld16 = [](const void* ptr) __attribute__((always_inline)) { return *reinterpret_cast<const u32x4*>(ptr); };
-  auto issue_loads = [&](int t, Blk blk) __attribute__((always_inline)) {
-    if constexpr (PREFIX) {
-      if (t < ctx_tiles) {
-        const int bsm = (1 << p.bs_shift) - 1;
-        const int slot = (t * BN + skey) & bsm;
-        const uint8_t* kb = p.k_cache + (int64_t)blk.k * p.kc_block_bytes + (int64_t)kvh * p.kc_head_bytes;
-        if constexpr (FP8) {
-          kst[0] = ld16(kb + (((spl << p.bs_shift) + slot) << 4));
-        } else {
-          kst[0] = ld16(kb + ((((2 * spl) << p.bs_shift) + slot) << 4));
-          kst[1] = ld16(kb + ((((2 * spl + (pv1 ? 1 : 0)) << p.bs_shift) + slot) << 4));
-        }
-        const int slot0 = (t * BN + 16 * vq) & bsm;
-        const uint8_t* vb = p.v_cache + (int64_t)blk.v * p.vc_block_bytes + (int64_t)kvh * p.vc_head_bytes +
-                            ((min(vd, dr - 1) << p.bs_shift) + slot0) * (FP8 ? 1 : 2);
-        vst[0] = ld16(vb);
-        if constexpr (!FP8) vst[1] = ld16(vb + 16);
-      } else {
-        const int64_t row = tok0 + min((t - ctx_tiles) * BN + skey, qlen - 1);
-        const T* kr = (const T*)p.k_new + row * p.k_stride_t + (int64_t)kvh * p.k_stride_h + 16 * spl;
-        const T* vr = (const T*)p.v_new + row * p.v_stride_t + (int64_t)kvh * p.v_stride_h + 16 * spl;
-        kst[0] = ld16(kr); kst[1] = ld16(kr + o1);
-        vst[0] = ld16(vr); vst[1] = ld16(vr + o1);
-      }
-    } else {
-      const int slot = (t * BN + skey) & ((1 << p.bs_shift) - 1);
-      const uint8_t* kr = p.k_cache + (int64_t)blk.k * p.kc_block_bytes + (int64_t)slot * p.kc_slot_bytes +
-                          (int64_t)kvh * p.kc_head_bytes + 16 * NST * spl;
-      const uint8_t* vr = p.v_cache + (int64_t)blk.k * p.vc_block_bytes + (int64_t)slot * p.vc_slot_bytes +
-                          (int64_t)kvh * p.vc_head_bytes + 16 * NST * spl;
+  auto issue_loads = [&](int t, const Blk& blk) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < NST; ++i) {
-        kst[i] = ld16(kr + (i ? 2 * o1 : 0));   // (fp8: one load; 16-bit: the second chunk 16 bytes on, if it exists)
-        vst[i] = ld16(vr + (i ? 2 * o1 : 0));
+    for (int i = 0; i < IPT; ++i) {
+      const int key = skey + KSTEP * i;
+      if constexpr (PREFIX) {
+        if (t < ctx_tiles) {
+          const int bsm = (1 << p.bs_shift) - 1;
+          const int slot = (t * BN + key) & bsm;
+          const uint8_t* kb = p.k_cache + (int64_t)blk.k[i] * p.kc_block_bytes + (int64_t)kvh * p.kc_head_bytes;
+          if constexpr (FP8) {
+            kst[i][0] = ld16(kb + (((spl << p.bs_shift) + slot) << 4));
+          } else {
+            kst[i][0] = ld16(kb + ((((2 * spl) << p.bs_shift) + slot) << 4));
+            kst[i][1] = ld16(kb + ((((2 * spl + (pv1 ? 1 : 0)) << p.bs_shift) + slot) << 4));
+          }
+          const int slot0 = (t * BN + 16 * vq_of(i)) & bsm;
+          const uint8_t* vb = p.v_cache + (int64_t)blk.v[i] * p.vc_block_bytes + (int64_t)kvh * p.vc_head_bytes +
+                              ((min(vd_of(i), dr - 1) << p.bs_shift) + slot0) * (FP8 ? 1 : 2);
+          vst[i][0] = ld16(vb);
+          if constexpr (!FP8) vst[i][1] = ld16(vb + 16);
+        } else {
+          const int64_t row = tok0 + min((t - ctx_tiles) * BN + key, qlen - 1);
+          const T* kr = (const T*)p.k_new + row * p.k_stride_t + (int64_t)kvh * p.k_stride_h + 16 * spl;
+          const T* vr = (const T*)p.v_new + row * p.v_stride_t + (int64_t)kvh * p.v_stride_h + 16 * spl;
+          kst[i][0] = ld16(kr); kst[i][1] = ld16(kr + o1);
+          vst[i][0] = ld16(vr); vst[i][1] = ld16(vr + o1);
+        }
+      } else {
+        const int slot = (t * BN + key) & ((1 << p.bs_shift) - 1);
+        const uint8_t* kr = p.k_cache + (int64_t)blk.k[i] * p.kc_block_bytes + (int64_t)slot * p.kc_slot_bytes +
+                            (int64_t)kvh * p.kc_head_bytes + 16 * NST * spl;
+        const uint8_t* vr = p.v_cache + (int64_t)blk.k[i] * p.vc_block_bytes + (int64_t)slot * p.vc_slot_bytes +
+                            (int64_t)kvh * p.vc_head_bytes + 16 * NST * spl;
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+          kst[i][j] = ld16(kr + (j ? 2 * o1 : 0));   // (fp8: one load; 16-bit: the second chunk 16 bytes on, if it exists)
+          vst[i][j] = ld16(vr + (j ? 2 * o1 : 0));
+        }
       }
     }
   };
   // K image: chunk ^= key & 15 (conflict-free ds_read_b128 of 32 keys x one chunk); V image: chunk ^= (key & 3) << 2
   // (the four keys of a transposing read land in four different 64-byte bank ranges); context V^T image (PREFIX):
-  // rows of 128 bytes = 64 tokens of one d, 8-byte unit ^= (d >> 1) & 15 (32 rows x one unit: every bank once)
+  // rows of 128 bytes = 64 tokens of one d, 8-byte unit ^= (d >> 1) & 15 (32 rows x one unit: every bank once).
+  // (the keys of a thread's items are KSTEP apart, a multiple of 16: one pair of swizzled chunk offsets for all)
   uint8_t* k_wr = lds + K_OFF + skey * ROWB;
   uint8_t* v_wr = lds + V_OFF + skey * ROWB;
   const int kc0 = ((2 * spiece) ^ (skey & 15)) << 4, kc1 = ((2 * spiece + 1) ^ (skey & 15)) << 4;
@@ -274,68 +294,73 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   auto write_tile = [&](int t) __attribute__((always_inline)) {
     const int kb_ = (t & (KN - 1)) * TILE, vb_ = (t & (VN - 1)) * TILE;
     const bool is_ctx = PREFIX && t < ctx_tiles;
-    // slots past the sequence hold stale bytes (possibly NaN): K and V rows of such keys are zeroed (their
-    // scores are 0 + the mask's -inf, their probabilities 0, and 0 * NaN = NaN)
-    const bool live = PREFIX ? (is_ctx ? t * BN + skey < ctx : (t - ctx_tiles) * BN + skey < qlen)
-                             : t * BN + skey < seq_len;
     const bool conv = FP8 && (!PREFIX || is_ctx);   // this tile's registers hold e4m3
-    u32x4 k0, k1, v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
-    if (conv) {
-      uint4 lo, hi4;
-      widen16<T>(u4(kst[0]), lo, hi4);
-      k0 = (u32x4){lo.x, lo.y, lo.z, lo.w};
-      k1 = (u32x4){hi4.x, hi4.y, hi4.z, hi4.w};
-    } else {
-      k0 = kst[0]; k1 = kst[NST - 1];
-    }
-    if (!live || !pv0) k0 = (u32x4){0, 0, 0, 0};
-    if (!live || !pv1) k1 = (u32x4){0, 0, 0, 0};
-    *reinterpret_cast<u32x4*>(k_wr + kb_ + kc0) = k0;
-    *reinterpret_cast<u32x4*>(k_wr + kb_ + kc1) = k1;
-    if (is_ctx) {
-      // V^T: the thread's 16 tokens of row vd = four 8-byte units
-      const int valid = vd < dr ? ctx - (t * BN + 16 * vq) : 0;
-      uint4 lo, hi4;
-      if constexpr (FP8) {
-        widen16<T>(mask_bytes(u4(vst[0]), valid), lo, hi4);
-      } else {
-        lo = mask_halfs(u4(vst[0]), valid);
-        hi4 = mask_halfs(u4(vst[NST - 1]), valid - 8);
-      }
-      uint8_t* row = lds + V_OFF + vb_ + vd * 128;
-      const int f = (vd >> 1) & 15;
-      *reinterpret_cast<u32x2*>(row + (((4 * vq + 0) ^ f) << 3)) = (u32x2){lo.x, lo.y};
-      *reinterpret_cast<u32x2*>(row + (((4 * vq + 1) ^ f) << 3)) = (u32x2){lo.z, lo.w};
-      *reinterpret_cast<u32x2*>(row + (((4 * vq + 2) ^ f) << 3)) = (u32x2){hi4.x, hi4.y};
-      *reinterpret_cast<u32x2*>(row + (((4 * vq + 3) ^ f) << 3)) = (u32x2){hi4.z, hi4.w};
-    } else {
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      const int key = skey + KSTEP * i;
+      // slots past the sequence hold stale bytes (possibly NaN): K and V rows of such keys are zeroed (their
+      // scores are 0 + the mask's -inf, their probabilities 0, and 0 * NaN = NaN)
+      const bool live = PREFIX ? (is_ctx ? t * BN + key < ctx : (t - ctx_tiles) * BN + key < qlen)
+                               : t * BN + key < seq_len;
+      u32x4 k0, k1, v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
       if (conv) {
         uint4 lo, hi4;
-        widen16<T>(u4(vst[0]), lo, hi4);
-        v0 = (u32x4){lo.x, lo.y, lo.z, lo.w};
-        v1 = (u32x4){hi4.x, hi4.y, hi4.z, hi4.w};
+        widen16<T>(u4(kst[i][0]), lo, hi4);
+        k0 = (u32x4){lo.x, lo.y, lo.z, lo.w};
+        k1 = (u32x4){hi4.x, hi4.y, hi4.z, hi4.w};
       } else {
-        v0 = vst[0]; v1 = vst[NST - 1];
+        k0 = kst[i][0]; k1 = kst[i][NST - 1];
       }
-      if (!live || !pv0) v0 = (u32x4){0, 0, 0, 0};
-      if (!live || !pv1) v1 = (u32x4){0, 0, 0, 0};
-      *reinterpret_cast<u32x4*>(v_wr + vb_ + vc0) = v0;
-      *reinterpret_cast<u32x4*>(v_wr + vb_ + vc1) = v1;
+      if (!live || !pv0) k0 = (u32x4){0, 0, 0, 0};
+      if (!live || !pv1) k1 = (u32x4){0, 0, 0, 0};
+      *reinterpret_cast<u32x4*>(k_wr + kb_ + KSTEP * i * ROWB + kc0) = k0;
+      *reinterpret_cast<u32x4*>(k_wr + kb_ + KSTEP * i * ROWB + kc1) = k1;
+      if (is_ctx) {
+        // V^T: the item's 16 tokens of row vd = four 8-byte units
+        const int vd = vd_of(i), vq = vq_of(i);
+        const int valid = vd < dr ? ctx - (t * BN + 16 * vq) : 0;
+        uint4 lo, hi4;
+        if constexpr (FP8) {
+          widen16<T>(mask_bytes(u4(vst[i][0]), valid), lo, hi4);
+        } else {
+          lo = mask_halfs(u4(vst[i][0]), valid);
+          hi4 = mask_halfs(u4(vst[i][NST - 1]), valid - 8);
+        }
+        uint8_t* row = lds + V_OFF + vb_ + vd * 128;
+        const int f = (vd >> 1) & 15;
+        *reinterpret_cast<u32x2*>(row + (((4 * vq + 0) ^ f) << 3)) = (u32x2){lo.x, lo.y};
+        *reinterpret_cast<u32x2*>(row + (((4 * vq + 1) ^ f) << 3)) = (u32x2){lo.z, lo.w};
+        *reinterpret_cast<u32x2*>(row + (((4 * vq + 2) ^ f) << 3)) = (u32x2){hi4.x, hi4.y};
+        *reinterpret_cast<u32x2*>(row + (((4 * vq + 3) ^ f) << 3)) = (u32x2){hi4.z, hi4.w};
+      } else {
+        if (conv) {
+          uint4 lo, hi4;
+          widen16<T>(u4(vst[i][0]), lo, hi4);
+          v0 = (u32x4){lo.x, lo.y, lo.z, lo.w};
+          v1 = (u32x4){hi4.x, hi4.y, hi4.z, hi4.w};
+        } else {
+          v0 = vst[i][0]; v1 = vst[i][NST - 1];
+        }
+        if (!live || !pv0) v0 = (u32x4){0, 0, 0, 0};
+        if (!live || !pv1) v1 = (u32x4){0, 0, 0, 0};
+        *reinterpret_cast<u32x4*>(v_wr + vb_ + KSTEP * i * ROWB + vc0) = v0;
+        *reinterpret_cast<u32x4*>(v_wr + vb_ + KSTEP * i * ROWB + vc1) = v1;
+      }
     }
   };
 
   // ---- fragment read addresses (lane constants; buffer, key block and key group are immediates) ---------
-  const uint8_t* k_rd[8];   // K rows l32 (+ 32 kb), chunk 2 ks + hi
+  const uint8_t* k_rd[KS];   // K rows l32 (+ 32 kb), chunk 2 ks + hi
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) k_rd[ks] = lds + K_OFF + l32 * ROWB + (((2 * ks + hi) ^ (l32 & 15)) << 4);
+  for (int ks = 0; ks < KS; ++ks) k_rd[ks] = lds + K_OFF + l32 * ROWB + (((2 * ks + hi) ^ (l32 & 15)) << 4);
   // transposing read: the 16 lanes of group G = lane >> 4 read keys 4 hi + (0..3) (+ 16 g16 + 8 e) x d
   // 32 db + 16 (G & 1) + (0..15); lane 4 q + pp of the group addresses key q, d 4 pp .. 4 pp + 3 and receives
   // d = 32 db + (lane & 31) of the four keys
-  const uint8_t* v_rd[4];
+  const uint8_t* v_rd[DB];
   {
     const int q = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < DB; ++db)
       v_rd[db] = lds + V_OFF + (4 * hi + q) * ROWB + ((4 * (db ^ q) + 2 * g1 + (pp >> 1)) << 4) + 8 * (pp & 1);
   }
 
@@ -345,9 +370,9 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   for (int i = 0; i < 8; ++i) vt_o[i] = V_OFF + l32 * 128 + (((2 * i + hi) ^ ((l32 >> 1) & 15)) << 3);
 
   float m_run = -INFINITY, l_run = 0.f;
-  f32x16 o[4];   // O^T[d = 32 db + (r & 3) + 8 (r >> 2) + 4 hi][this row]
+  f32x16 o[DB];   // O^T[d = 32 db + (r & 3) + 8 (r >> 2) + 4 hi][this row]
 #pragma unroll
-  for (int db = 0; db < 4; ++db)
+  for (int db = 0; db < DB; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
 
@@ -376,17 +401,17 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   const int kofs = (t & (KN - 1)) * TILE;
   const int vofs = (t & (VN - 1)) * TILE;
   auto k_read = [&](auto ic, int kofs) __attribute__((always_inline)) {
-    constexpr int i = decltype(ic)::value;   // read i -> (key block i >> 3, k-step i & 7)
-    return *reinterpret_cast<const u32x4*>(k_rd[i & 7] + kofs + (i >> 3) * 32 * ROWB);
+    constexpr int i = decltype(ic)::value;   // read i -> (key block i / KS, k-step i % KS)
+    return *reinterpret_cast<const u32x4*>(k_rd[i % KS] + kofs + (i / KS) * 32 * ROWB);
   };
   static_for<KR>([&](auto ic) { kf[decltype(ic)::value] = k_read(ic, kofs); });
   __builtin_amdgcn_sched_barrier(0);
   float mx = 0.f;   // running maximum of the tile's raw scores in this lane
   {
-    static_for<16>([&](auto ic) {
-      constexpr int i = decltype(ic)::value, kb = i >> 3, ks = i & 7;
+    static_for<2 * KS>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, kb = i / KS, ks = i % KS;
       const u32x4 f = kf[i % KR];
-      if constexpr (i + KR < 16) kf[i % KR] = k_read(std::integral_constant<int, i + KR>{}, kofs);
+      if constexpr (i + KR < 2 * KS) kf[i % KR] = k_read(std::integral_constant<int, i + KR>{}, kofs);
       if constexpr (ks == 0) {
         // the accumulator starts at 0, or at -inf where the key is invisible to this row: the mask rides in the
         // MFMA's C operand (K rows past the sequence are staged as zeros, so nothing there is NaN or inf)
@@ -402,7 +427,7 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
       } else {
         if (!(abl & 4)) s[kb] = Mma32<T>::mfma(f, qf[ks], s[kb]);
       }
-      if constexpr (kb == 1) {   // block 0 is complete: its maximum, two scores per MFMA
+      if constexpr (kb == 1 && ks < 8) {   // block 0 is complete: its maximum, two scores per MFMA
         if constexpr (ks == 0) mx = max3(s[0][0], s[0][1], s[0][1]);
         else mx = max3(mx, s[0][2 * ks], s[0][2 * ks + 1]);
       }
@@ -412,14 +437,14 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   FA_T(2);
   u32x4 vf[VR];
   auto v_read = [&](auto ic, int vofs) __attribute__((always_inline)) {
-    constexpr int i = decltype(ic)::value;   // MFMA i -> (key group i >> 2, d block i & 3)
+    constexpr int i = decltype(ic)::value;   // MFMA i -> (key group i / DB, d block i % DB)
     if constexpr (VT) {
-      const u32x2 va = *reinterpret_cast<const u32x2*>(lds + vt_o[2 * (i >> 2)] + vofs + 4096 * (i & 3));
-      const u32x2 vb = *reinterpret_cast<const u32x2*>(lds + vt_o[2 * (i >> 2) + 1] + vofs + 4096 * (i & 3));
+      const u32x2 va = *reinterpret_cast<const u32x2*>(lds + vt_o[2 * (i / DB)] + vofs + 4096 * (i % DB));
+      const u32x2 vb = *reinterpret_cast<const u32x2*>(lds + vt_o[2 * (i / DB) + 1] + vofs + 4096 * (i % DB));
       return (u32x4){va[0], va[1], vb[0], vb[1]};
     } else {
-      const u32x2 va = lds_tr16(v_rd[i & 3] + vofs + (16 * (i >> 2)) * ROWB);
-      const u32x2 vb = lds_tr16(v_rd[i & 3] + vofs + (16 * (i >> 2) + 8) * ROWB);
+      const u32x2 va = lds_tr16(v_rd[i % DB] + vofs + (16 * (i / DB)) * ROWB);
+      const u32x2 vb = lds_tr16(v_rd[i % DB] + vofs + (16 * (i / DB) + 8) * ROWB);
       return (u32x4){va[0], va[1], vb[0], vb[1]};
     }
   };
@@ -436,7 +461,7 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
       m_run = m_new;
       l_run *= alpha;
 #pragma unroll
-      for (int db = 0; db < 4; ++db)
+      for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
     }
@@ -454,12 +479,12 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
     static_for<4>([&](auto jc) { p_word(std::integral_constant<int, 0>{}, jc); });
     __builtin_amdgcn_sched_barrier(0);
     // O^T += V^T . P^T
-    static_for<16>([&](auto ic) {
-      constexpr int i = decltype(ic)::value, g16 = i >> 2, db = i & 3;
+    static_for<4 * DB>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, g16 = i / DB, db = i % DB;
       const u32x4 f = vf[i % VR];
-      if constexpr (i + VR < 16) vf[i % VR] = v_read(std::integral_constant<int, i + VR>{}, vofs);
+      if constexpr (i + VR < 4 * DB) vf[i % VR] = v_read(std::integral_constant<int, i + VR>{}, vofs);
       if (!(abl & 8) || i < 4) o[db] = Mma32<T>::mfma(f, pb[g16], o[db]);
-      if constexpr (g16 + 1 < 4) p_word(std::integral_constant<int, g16 + 1>{}, std::integral_constant<int, db>{});
+      if constexpr (g16 + 1 < 4 && db < 4) p_word(std::integral_constant<int, g16 + 1>{}, std::integral_constant<int, db>{});
       __builtin_amdgcn_sched_barrier(0);
     });
     l_run += TILE_FP8 ? psum * vinv : psum;   // the sum in units of the unscaled probabilities
@@ -489,7 +514,7 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   // the first one at the bottom: while one wave converts, writes and computes addresses, its partner is in its
   // MFMA sections (all eight waves in step leave the matrix pipe idle during the staging and collide in it
   // otherwise: in-kernel stamps showed tile time = MFMA time + everything else, no overlap at all).
-  const bool stage_first = (p.stagger & 1) && wave >= NW / 2;
+  const bool stage_first = (p.stagger & 1) && NW == 8 && wave >= NW / 2;   // (one wave per SIMD: nothing to stagger)
   // ("pf_fa_stagger" bits 1 / 2, measurement: a static priority for waves 4-7 / 0-3)
   if ((p.stagger & 2) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
   if ((p.stagger & 4) && wave < NW / 2) __builtin_amdgcn_s_setprio(1);
@@ -563,7 +588,7 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
   if (p.out_scale == nullptr) {
     T* op = (T*)p.o + (int64_t)(tok0 + rtok) * p.o_stride_t + (int64_t)rhead * p.o_stride_h + 4 * hi;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const u32x2 w = {Mma<T>::pack2(o[db][4 * rq] * inv, o[db][4 * rq + 1] * inv),
@@ -574,7 +599,7 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
     const float oinv = inv / *p.out_scale;   // acc / l / out_scale, clamped to the e4m3 range (:282-287)
     uint8_t* op = (uint8_t*)p.o + (int64_t)(tok0 + rtok) * p.o_stride_t + (int64_t)rhead * p.o_stride_h + 4 * hi;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         float yv[4];
@@ -590,17 +615,25 @@ __global__ __launch_bounds__(64 * NW) void fa_fwd_kernel(const FaParams p) {
 
 int g_pf_fa_stagger = 1;   // tuning "pf_fa_stagger": 0 = all eight waves stage at the bottom of the interval
 int launch_unified_fa(const FaParams& p, int dtype, bool fp8, hipStream_t st) {
-  const int tpb = fa::BM / p.pack;
+  const bool wide = p.head_size > 128;                 // 128-row workgroups of four waves
+  const int tpb = (wide ? 128 : 256) / p.pack;
   const unsigned gx = p.blocks_per_seq > 0 ? (unsigned)(p.blocks_per_seq * p.num_seqs) : (unsigned)(p.num_tokens / tpb + p.num_seqs);
   const dim3 grid(gx, (unsigned)(p.pack > 1 ? p.num_kv_heads : p.num_heads));
-#define FA_LAUNCH(T_, F_)                                                                              \
-  do {                                                                                                 \
-    if (p.prefix) hipLaunchKernelGGL((fa::fa_fwd_kernel<T_, F_, true>), grid, dim3(64 * fa::NW), 0, st, p);  \
-    else hipLaunchKernelGGL((fa::fa_fwd_kernel<T_, F_, false>), grid, dim3(64 * fa::NW), 0, st, p);   \
+#define FA_LAUNCH__(T_, F_, P_, D_, NW_) \
+  hipLaunchKernelGGL((fa::fa_fwd_kernel<T_, F_, P_, D_, NW_>), grid, dim3(64 * NW_), 0, st, p)
+#define FA_LAUNCH_(T_, F_, P_)                                                          \
+  do {                                                                                  \
+    if (wide) FA_LAUNCH__(T_, F_, P_, 256, 4); else FA_LAUNCH__(T_, F_, P_, 128, 8);    \
+  } while (0)
+#define FA_LAUNCH(T_, F_)                                                   \
+  do {                                                                      \
+    if (p.prefix) FA_LAUNCH_(T_, F_, true); else FA_LAUNCH_(T_, F_, false); \
   } while (0)
   if (dtype == VLLM_AMD_BF16) { if (fp8) FA_LAUNCH(bf16_t, true); else FA_LAUNCH(bf16_t, false); }
   else { if (fp8) FA_LAUNCH(f16_t, true); else FA_LAUNCH(f16_t, false); }
 #undef FA_LAUNCH
+#undef FA_LAUNCH_
+#undef FA_LAUNCH__
   return VLLM_AMD_OK;
 }
 
