@@ -54,7 +54,12 @@ template <> struct Mma32<f16_t> {
 
 constexpr int BN = 64;            // keys per tile
 constexpr int KN = 2, VN = 2;     // K / V tiles in LDS (rings indexed by the tile number)
-constexpr int KR = 8, VR = 4;     // fragment reads in flight: K reads, V^T fragments (two transposing reads each)
+#ifndef FA_KRW
+#define FA_KRW 8
+#define FA_VRW 4
+#endif
+constexpr int KR128 = 8, VR128 = 4;   // fragment reads in flight: K reads, V^T fragments (two transposing reads each)
+constexpr int KR256 = FA_KRW, VR256 = FA_VRW;
 constexpr float THR = 8.f;        // lazy rescale threshold (log2 domain)
 
 __device__ __forceinline__ float max3(float a, float b, float c) {
@@ -115,10 +120,11 @@ __global__ __launch_bounds__(64 * NW_) void fa_fwd_kernel(const FaParams p) {
   constexpr int TILE = BN * ROWB;   // 16 / 32 KiB
   constexpr int K_OFF = 0, V_OFF = KN * TILE;
   constexpr int KS = D / 16, DB = D / 32;         // k-steps of S^T, d blocks of O^T
+  constexpr int KR = D > 128 ? KR256 : KR128, VR = D > 128 ? VR256 : VR128;
   constexpr int PPK = D / 16;                     // 32-byte staging pieces per key
   constexpr int NTHR = 64 * NW, IPT = BN * PPK / NTHR, KSTEP = NTHR / PPK;   // staging items per thread, keys between them
   static_assert(IPT * NTHR == BN * PPK && (IPT == 1 || KSTEP % 16 == 0) && 4 * D == IPT * NTHR, "");
-  __shared__ __attribute__((aligned(16))) uint8_t lds[(KN + VN) * TILE];   // 64 / 128 KiB
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[(KN + VN) * TILE];   // 64 / 128 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, hi = lane >> 5;
@@ -364,6 +370,10 @@ __global__ __launch_bounds__(64 * NW_) void fa_fwd_kernel(const FaParams p) {
       v_rd[db] = lds + V_OFF + (4 * hi + q) * ROWB + ((4 * (db ^ q) + 2 * g1 + (pp >> 1)) << 4) + 8 * (pp & 1);
   }
 
+  // (D = 256: the same addresses from one offset each, XORed with the k-step / d block / unit at the read)
+  const int k_off0 = K_OFF + l32 * ROWB + ((hi ^ (l32 & 15)) << 4);
+  const int v_off0 = V_OFF + (4 * hi + ((lane & 15) >> 2)) * ROWB + ((4 * ((lane & 15) >> 2) + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1)) << 4) +
+                     8 * (lane & 1);
   // context V^T (PREFIX): row d = 32 db + l32, unit 4 g16 + 2 e + hi = tokens 16 g16 + 8 e + 4 hi .. + 3
   int vt_o[8];
 #pragma unroll
@@ -402,7 +412,10 @@ __global__ __launch_bounds__(64 * NW_) void fa_fwd_kernel(const FaParams p) {
   const int vofs = (t & (VN - 1)) * TILE;
   auto k_read = [&](auto ic, int kofs) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;   // read i -> (key block i / KS, k-step i % KS)
-    return *reinterpret_cast<const u32x4*>(k_rd[i % KS] + kofs + (i / KS) * 32 * ROWB);
+    if constexpr (D > 128)   // one base offset, the k-step XORed in (the tile is 1 KiB aligned): 15 registers fewer
+      return *reinterpret_cast<const u32x4*>(lds + ((k_off0 ^ ((i % KS) << 5)) + kofs + (i / KS) * 32 * ROWB));
+    else
+      return *reinterpret_cast<const u32x4*>(k_rd[i % KS] + kofs + (i / KS) * 32 * ROWB);
   };
   static_for<KR>([&](auto ic) { kf[decltype(ic)::value] = k_read(ic, kofs); });
   __builtin_amdgcn_sched_barrier(0);
@@ -439,12 +452,15 @@ __global__ __launch_bounds__(64 * NW_) void fa_fwd_kernel(const FaParams p) {
   auto v_read = [&](auto ic, int vofs) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;   // MFMA i -> (key group i / DB, d block i % DB)
     if constexpr (VT) {
-      const u32x2 va = *reinterpret_cast<const u32x2*>(lds + vt_o[2 * (i / DB)] + vofs + 4096 * (i % DB));
-      const u32x2 vb = *reinterpret_cast<const u32x2*>(lds + vt_o[2 * (i / DB) + 1] + vofs + 4096 * (i % DB));
+      const int oa = D > 128 ? (vt_o[0] ^ ((2 * (i / DB)) << 4)) : vt_o[2 * (i / DB)];
+      const int ob = D > 128 ? (vt_o[0] ^ ((2 * (i / DB) + 1) << 4)) : vt_o[2 * (i / DB) + 1];
+      const u32x2 va = *reinterpret_cast<const u32x2*>(lds + oa + vofs + 4096 * (i % DB));
+      const u32x2 vb = *reinterpret_cast<const u32x2*>(lds + ob + vofs + 4096 * (i % DB));
       return (u32x4){va[0], va[1], vb[0], vb[1]};
     } else {
-      const u32x2 va = lds_tr16(v_rd[i % DB] + vofs + (16 * (i / DB)) * ROWB);
-      const u32x2 vb = lds_tr16(v_rd[i % DB] + vofs + (16 * (i / DB) + 8) * ROWB);
+      const uint8_t* vp = D > 128 ? lds + ((v_off0 ^ ((i % DB) << 6)) + vofs) : v_rd[i % DB] + vofs;
+      const u32x2 va = lds_tr16(vp + (16 * (i / DB)) * ROWB);
+      const u32x2 vb = lds_tr16(vp + (16 * (i / DB) + 8) * ROWB);
       return (u32x4){va[0], va[1], vb[0], vb[1]};
     }
   };
