@@ -494,8 +494,8 @@ int vllm_amd_ar_free_shared(void* ptr);
 /*   "uni_decode": 0 = unified_attention never uses its decode kernel (1 =     */
 /*                 default; 2 / 3 = XCD-grouped workgroup order always / never) */
 /*   "pf_fa":      the 256-row kernel of unified_attention /                   */
-/*                 context_attention_fwd (prefill_fa.hip; head sizes 72 .. 128, */
-/*                 causal mask, unified: + sliding window): 0 = for launches whose longest query chunk fills */
+/*                 context_attention_fwd (prefill_fa.hip; head sizes 72 .. 256, */
+/*                 causal mask, unified: + sliding window, softcap): 0 = for launches whose longest query chunk fills */
 /*                 a row block (default), 1 = never, 2 = whenever it applies   */
 /*   "pf_fa_stagger": 0 = all eight waves of that kernel stage in step (1 =    */
 /*                 default: waves 4-7 at the top of the tile interval)         */

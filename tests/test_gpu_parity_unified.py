@@ -446,3 +446,16 @@ def test_unified_fa_kernel_head_sizes(oracle, force_fa, D, fp8, dtype):
         run(oracle, c, dtype, fp8=fp8)
         c = make_unified_case([(200, 333), (64, 64)], 4, 4, D, 16, dtype, fp8=fp8, seed=2, kv_scale=0.5)
         run(oracle, c, dtype, fp8=fp8, out_scale=torch.tensor([0.03]))
+
+
+@pytest.mark.parametrize("soft_cap", [10.0, 50.0])
+@pytest.mark.parametrize("D", [128, 256, 96])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("window", [None, 100])
+def test_unified_fa_kernel_softcap(oracle, force_fa, soft_cap, D, fp8, window):
+    """Soft-capped scores (Gemma-2: 50 with head 256 and alternating sliding windows) in the 256-row kernel: interior and
+    masked tiles (a masked score must stay -inf, not -softcap), both head widths, fp8 cache."""
+    for dtype in (torch.bfloat16, torch.float16):
+        c = make_unified_case([(300, 700), (129, 463), (1, 90), (70, 70)], 8, 2, D, 16, dtype, fp8=fp8,
+                              seed=int(soft_cap) + D, kv_scale=0.5)
+        run(oracle, c, dtype, fp8=fp8, softcap=soft_cap, window=window)

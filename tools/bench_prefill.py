@@ -14,6 +14,7 @@ ap.add_argument("--unified", action="store_true", help="unified_attention over a
 ap.add_argument("--rows", type=int, default=0, help="query rows per workgroup (tuning pf_rows)")
 ap.add_argument("--hnd", action="store_true", help="unified: head-major cache memory (permuted view)")
 ap.add_argument("--shapes", default="4x2048x0,4x2048x2048,1x8192x0,16x512x3584,64x128x4096", help="BxQxCTX,...")
+ap.add_argument("--softcap", type=float, default=0.0, help="unified: soft cap of the scores")
 ap.add_argument("--window", type=int, default=0, help="unified: sliding window (keys)")
 ap.add_argument("--D", type=int, default=128, help="head size")
 ap.add_argument("--set", default="", help="tuning keys: k=v[,k=v]")
@@ -65,7 +66,7 @@ for (B, ql, cl) in [tuple(int(x) for x in sh.split('x')) for sh in a.shapes.spli
             vf = vf.view(B * nb_u, KVH, BS, D).permute(0, 2, 1, 3)
         bt = torch.randperm(B * nb_u, device=dev).to(torch.int32).view(B, nb_u)
         fn = lambda: unified_attention(q, kf, vf, o, start, ql, seql, ql + cl, D ** -0.5, True, ((a.window - 1, 0) if a.window else (-1, -1)),
-                                       bt, 0.0, None, one if fp8 else None, one if fp8 else None)
+                                       bt, a.softcap, None, one if fp8 else None, one if fp8 else None)
     t = bench.time_gpu_graph(fn, a.iters)
     flops = 4.0 * D * H * B * ql * (cl + (ql + 1) / 2)
     print(f"{'unified ' if a.unified else ''}B={B:3d} q_len={ql:5d} ctx={cl:5d} kv={a.kv}: {t*1e6:9.1f} us  {flops/t/1e12:7.1f} TFLOP/s "

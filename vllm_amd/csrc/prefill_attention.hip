@@ -816,7 +816,7 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
   {
     const int pack = (gqa > 1 && gqa <= 16) ? gqa : 1;
     const int fa_rows = head_size > 128 ? 128 : 256;   // rows of a workgroup: four waves at head sizes above 128
-    const bool can = head_size > 64 && head_size <= 256 && p.alibi_slopes == nullptr && p.softcap == 0.f &&
+    const bool can = head_size > 64 && head_size <= 256 && p.alibi_slopes == nullptr &&
                      p.flat_batch > 0 && p.sm_scale > 0.f && g_pf_rows == 0;
     // ... and the launch has enough 256-row blocks for the chip: below ~128 of them the 64-row kernel's four times as
     // many workgroups finish sooner (chunk 256 over 4096 cached tokens among 255 decodes: 32 blocks, 82 vs 150 us)
@@ -834,7 +834,7 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
       f.kc_block_bytes = p.kc_block_bytes; f.kc_slot_bytes = p.kc_page_bytes; f.kc_head_bytes = p.kc_head_bytes;
       f.vc_block_bytes = p.vc_block_bytes; f.vc_slot_bytes = p.vc_page_bytes; f.vc_head_bytes = p.vc_head_bytes;
       f.sm_scale = p.sm_scale;
-      f.window = p.sliding_window;
+      f.window = p.sliding_window; f.softcap = p.softcap;
       f.prefix = 0; f.k_new = f.v_new = nullptr; f.k_stride_t = f.k_stride_h = f.v_stride_t = f.v_stride_h = 0;
       f.blocks_per_seq = 0;
       f.abl = g_pf_fa_abl;
@@ -913,7 +913,7 @@ static void launch_d(const PrefillParams& p, int head_size, int block_size, int 
       f.kc_block_bytes = p.kc_block_bytes; f.kc_slot_bytes = 0; f.kc_head_bytes = p.kc_head_bytes;
       f.vc_block_bytes = p.vc_block_bytes; f.vc_slot_bytes = 0; f.vc_head_bytes = p.vc_head_bytes;
       f.sm_scale = p.sm_scale;
-      f.window = 0;
+      f.window = 0; f.softcap = 0.f;
       f.prefix = 1; f.k_new = p.k; f.v_new = p.v;
       f.k_stride_t = p.k_stride_t; f.k_stride_h = p.k_stride_h; f.v_stride_t = p.v_stride_t; f.v_stride_h = p.v_stride_h;
       const int tpb = fa_rows / pack;

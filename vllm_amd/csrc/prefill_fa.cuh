@@ -12,13 +12,14 @@ struct FaParams {
   const float* k_scale; const float* v_scale;             // fp8 cache only
   const float* out_scale;                                  // != null: e4m3 output
   int num_heads, num_kv_heads, num_seqs, num_tokens;
-  int head_size;       // 72 .. 128 (padded to 128 inside the kernel)
+  int head_size;       // 72 .. 256 (padded to 128, above 128 to 256, inside the kernel)
   int bs_shift;        // log2(block size)
   int skip_decode;     // sequences of query length 1 were taken by the decode kernel
   int pack;            // q heads per tile-row group: the GQA group (rows = (token, head) pairs) or 1
   int64_t bt_stride, q_stride_t, q_stride_h, o_stride_t, o_stride_h;
   int64_t kc_block_bytes, kc_slot_bytes, kc_head_bytes, vc_block_bytes, vc_slot_bytes, vc_head_bytes;
   float sm_scale;
+  float softcap;       // unified_attention: scores softcap * tanh(score / softcap); 0 = none (prefix: 0)
   int window;          // unified_attention: 1 + window_size[0] of the reference call, 0 = none (prefix: 0)
   // context_attention_fwd (prefix = 1): the caches are the paged CONTEXT in the x layout -- K [block][kv head][D / x][BS][x]
   // (x = 16 bytes), V [block][kv head][D][BS]; kc / vc_slot_bytes unused -- and the new tokens' keys / values are dense

@@ -113,7 +113,9 @@ __device__ unsigned long long g_fa_stamps[2048 * 8 * 8];
 // D_ = 128, NW_ = 8: head sizes 72 .. 128, eight waves = 256 rows, two waves per SIMD.
 // D_ = 256, NW_ = 4: head sizes 136 .. 256: O^T alone is 128 registers for a wave's 32 rows and Q^T 64, so a wave takes a
 // whole SIMD's register file: four waves = 128 rows, one per SIMD, 32 KiB tiles (128 KiB of LDS), 32 + 32 MFMAs per tile.
-template <typename T, bool FP8, bool PREFIX, int D_, int NW_>
+// SOFTCAP (unified_attention): scores softcap * tanh(score / softcap) (triton_unified_attention.py:219-221): a pass of
+// ~9 VALU per score between S^T and the softmax, in its own instantiation.
+template <typename T, bool FP8, bool PREFIX, int D_, int NW_, bool SOFTCAP>
 __global__ __launch_bounds__(64 * NW_) void fa_fwd_kernel(const FaParams p) {
   constexpr int NW = NW_, BM = 32 * NW, D = D_;
   constexpr int ROWB = 2 * D;       // bytes per LDS row (one key, D 16-bit values)
@@ -403,7 +405,8 @@ __global__ __launch_bounds__(64 * NW_) void fa_fwd_kernel(const FaParams p) {
   constexpr bool MASKED = decltype(masked_c)::value;
   constexpr bool VT = decltype(vt_c)::value;               // a context tile of the PREFIX kernel
   constexpr bool TILE_FP8 = FP8 && (!PREFIX || VT);        // the tile's K / V were e4m3
-  const float sct = TILE_FP8 ? sc2k : sc2;
+  const float sct0 = TILE_FP8 ? sc2k : sc2;            // raw score -> log2 domain
+  const float sct = SOFTCAP ? 1.f : sct0;                // (soft-capped scores are rewritten in the log2 domain)
   const int bound0 = VT ? bound_ctx - t * BN : bound_new - (t - ctx_tiles) * BN;
   f32x16 s[2];
   u32x4 pb[4];   // P^T fragments of key groups 16 g16 ..: slots 0-3 = keys 4 hi + (0..3), 4-7 = 8 + 4 hi + (0..3)
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(64 * NW_) void fa_fwd_kernel(const FaParams p) {
       } else {
         if (!(abl & 4)) s[kb] = Mma32<T>::mfma(f, qf[ks], s[kb]);
       }
-      if constexpr (kb == 1 && ks < 8) {   // block 0 is complete: its maximum, two scores per MFMA
+      if constexpr (kb == 1 && ks < 8 && !SOFTCAP) {   // block 0 is complete: its maximum, two scores per MFMA
         if constexpr (ks == 0) mx = max3(s[0][0], s[0][1], s[0][1]);
         else mx = max3(mx, s[0][2 * ks], s[0][2 * ks + 1]);
       }
@@ -468,6 +471,25 @@ __global__ __launch_bounds__(64 * NW_) void fa_fwd_kernel(const FaParams p) {
     static_for<VR>([&](auto ic) { vf[decltype(ic)::value] = v_read(ic, vofs); });
     __builtin_amdgcn_sched_barrier(0);
     // lane holds S^T[key = 64 t + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi][this row]
+    if constexpr (SOFTCAP) {
+      // x = cap2 tanh(y), y = score / softcap, cap2 = softcap log2 e; tanh from one exp2 of -2 |y| and one rcp.  A
+      // masked score (-inf) would come out as -cap2: kept at -inf.
+      const float cap2 = p.softcap * kLog2e, c1 = sct0 / cap2;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float raw = s[kb][r];
+          const float y = raw * c1;
+          const float e2 = fast_exp2(-2.0f * kLog2e * fabsf(y));
+          const float th = (1.0f - e2) * __builtin_amdgcn_rcpf(1.0f + e2);
+          const float x = copysignf(cap2 * th, y);
+          s[kb][r] = (MASKED && raw == -INFINITY) ? -INFINITY : x;
+        }
+      mx = max3(s[0][0], s[0][1], s[0][1]);
+#pragma unroll
+      for (int r = 2; r < 16; r += 2) mx = max3(mx, s[0][r], s[0][r + 1]);
+    }
 #pragma unroll
     for (int r = 0; r < 16; r += 2) mx = max3(mx, s[1][r], s[1][r + 1]);
     const float ms = xmax(mx) * sct;
@@ -635,8 +657,13 @@ int launch_unified_fa(const FaParams& p, int dtype, bool fp8, hipStream_t st) {
   const int tpb = (wide ? 128 : 256) / p.pack;
   const unsigned gx = p.blocks_per_seq > 0 ? (unsigned)(p.blocks_per_seq * p.num_seqs) : (unsigned)(p.num_tokens / tpb + p.num_seqs);
   const dim3 grid(gx, (unsigned)(p.pack > 1 ? p.num_kv_heads : p.num_heads));
-#define FA_LAUNCH__(T_, F_, P_, D_, NW_) \
-  hipLaunchKernelGGL((fa::fa_fwd_kernel<T_, F_, P_, D_, NW_>), grid, dim3(64 * NW_), 0, st, p)
+#define FA_LAUNCH___(T_, F_, P_, D_, NW_, S_) \
+  hipLaunchKernelGGL((fa::fa_fwd_kernel<T_, F_, P_, D_, NW_, S_>), grid, dim3(64 * NW_), 0, st, p)
+#define FA_LAUNCH__(T_, F_, P_, D_, NW_)                                                           \
+  do {                                                                                             \
+    if (!P_ && p.softcap > 0.f) FA_LAUNCH___(T_, F_, false, D_, NW_, true);                        \
+    else FA_LAUNCH___(T_, F_, P_, D_, NW_, false);                                                 \
+  } while (0)
 #define FA_LAUNCH_(T_, F_, P_)                                                          \
   do {                                                                                  \
     if (wide) FA_LAUNCH__(T_, F_, P_, 256, 4); else FA_LAUNCH__(T_, F_, P_, 128, 8);    \
@@ -650,6 +677,7 @@ int launch_unified_fa(const FaParams& p, int dtype, bool fp8, hipStream_t st) {
 #undef FA_LAUNCH
 #undef FA_LAUNCH_
 #undef FA_LAUNCH__
+#undef FA_LAUNCH___
   return VLLM_AMD_OK;
 }
 
