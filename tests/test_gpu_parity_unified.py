@@ -176,11 +176,11 @@ def test_unified_decode_kernel(oracle, dtype, block_size, fp8, nseq):
     run(oracle, c, dtype, fp8=fp8)
 
 
-@pytest.mark.parametrize("D", [32, 48, 80, 96, 112, 120])
+@pytest.mark.parametrize("D", [32, 48, 80, 96, 112, 120, 136, 160, 192, 224, 256])
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("nseq", [5, 260])
 def test_unified_decode_head_sizes(oracle, D, fp8, nseq):
-    """Head sizes below the kernel's padded 64 / 128 (whole 16-byte K chunks): split and unsplit
+    """Head sizes below the kernel's padded 64 / 128 / 256 (whole 16-byte K chunks): split and unsplit
     launches, and a mixed batch of >= 16 sequences."""
     if fp8 and D % 16:
         pytest.skip("an fp8 cache needs head sizes that are multiples of 16")
@@ -219,6 +219,24 @@ def test_unified_decode_kernel_features(oracle, mode, fp8):
     slopes = 2.0 ** -(torch.arange(8).float() * 0.25 + 1) if mode == "alibi" else None
     view = (lambda t: t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)) if mode == "hnd" else None
     run(oracle, c, torch.bfloat16, fp8=fp8, alibi=slopes, window=100 if mode == "window" else None,
+        softcap=15.0 if mode == "softcap" else 0.0,
+        out_scale=torch.tensor([0.02]) if mode == "fp8_out" else None, view=view)
+
+
+@pytest.mark.parametrize("mode", ["window", "alibi", "softcap", "fp8_out", "hnd", "f16", "mqa"])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("nseq", [6, 300])
+def test_unified_decode_kernel_wide_heads(oracle, mode, fp8, nseq):
+    """The decode kernel's 256-wide instantiation (head sizes 136 .. 256: one workgroup per CU, the 16 q heads
+    written in two passes): split (6 sequences) and unsplit launches, every feature, groups of 16 and 20 q heads."""
+    lens = [5, 100, 129, 300, 640, 1000]
+    seqs = [(1, lens[i % len(lens)] + i // 6) for i in range(nseq)]
+    dtype = torch.float16 if mode == "f16" else torch.bfloat16
+    H, KVH = (20, 1) if mode == "mqa" else (16, 2) if mode == "hnd" else (8, 4)
+    c = make_unified_case(seqs, H, KVH, 192 if mode == "alibi" else 256, 16, dtype, fp8=fp8, seed=78 + nseq, kv_scale=0.5)
+    slopes = 2.0 ** -(torch.arange(H).float() * 0.25 + 1) if mode == "alibi" else None
+    view = (lambda t: t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)) if mode == "hnd" else None
+    run(oracle, c, dtype, fp8=fp8, alibi=slopes, window=100 if mode == "window" else None,
         softcap=15.0 if mode == "softcap" else 0.0,
         out_scale=torch.tensor([0.02]) if mode == "fp8_out" else None, view=view)
 

@@ -795,11 +795,12 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
       if (cap > p.num_segments) cap = p.num_segments;
       if (cap > 16) cap = 16;
       const float ovh = 160.f / (float)(max_k > 0 ? max_k : 1);
-      auto cost = [&](int n) { return (float)((wgs * n + 511) / 512) / n * (1.f + n * ovh); };
+      const int slots = head_size > 128 ? 256 : 512;   // head sizes above 128: one workgroup per CU (registers)
+      auto cost = [&](int n) { return (float)((wgs * n + slots - 1) / slots) / n * (1.f + n * ovh); };
       float best = 1e30f;
       for (int n = 1; n <= cap; ++n) best = cost(n) < best ? cost(n) : best;
       nseg = cap;
-      if (wgs * cap > 512)
+      if (wgs * cap > slots)
         for (int n = 1; n <= cap; ++n)
           if (cost(n) <= best * 1.05f) { nseg = n; break; }
     }

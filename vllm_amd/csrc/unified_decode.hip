@@ -43,6 +43,7 @@ template <int N> struct DwVec;
 template <> struct DwVec<1> { typedef unsigned int type; };
 template <> struct DwVec<2> { typedef u32x2 type; };
 template <> struct DwVec<4> { typedef u32x4 type; };
+template <> struct DwVec<8> { typedef __attribute__((ext_vector_type(8))) unsigned int type; };   // head 256, 16-bit cache
 template <int N>
 __device__ __forceinline__ unsigned int dw_get(const typename DwVec<N>::type& v, int i) {
   if constexpr (N == 1) return v;
@@ -54,7 +55,7 @@ __device__ __forceinline__ typename DwVec<N>::type nt_load(const uint8_t* p) {
 }
 
 template <typename T, bool FP8, int D, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodeParams p, int sub_shift, int xcd_group, int order) {
+__global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void ua_decode_kernel(const UniDecodeParams p, int sub_shift, int xcd_group, int order) {
   constexpr int ES = FP8 ? 1 : 2;             // cache element bytes
   constexpr int TILES = FP8 ? 4 : 2;          // 16-token tiles per step
   constexpr int STEP_TOK = TILES * 16;
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   constexpr int KL = D * ES / 64;             // K loads per tile and lane (16 B each)
   constexpr int VDW = DT * ES / 4;            // dwords of one token's V row a lane owns
   constexpr int QF = D / 32;                  // k-steps of the QK product
-  static_assert(VDW == 1 || VDW == 2 || VDW == 4, "");
+  static_assert(VDW == 1 || VDW == 2 || VDW == 4 || VDW == 8, "");
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
   const int seg = blockIdx.y;
   const int G = min(16, Gall - 16 * chunk);   // q heads of this workgroup
   const int head0 = kvh * Gall + 16 * chunk;
-  // D = head size padded to 64 / 128: chunks at d >= dr are never loaded (zeros: no contribution to
+  // D = head size padded to 64 / 128 / 256: chunks at d >= dr are never loaded (zeros: no contribution to
   // the scores, output columns that are never stored)
   const int dr = p.head_size;
 
@@ -371,49 +372,51 @@ __global__ __launch_bounds__(NW * 64, 2) void ua_decode_kernel(const UniDecodePa
     for (int r = 0; r < 4; ++r) om[(wave * D + DT * (4 * g4 + r) + j) * 16 + c16] = o[j][r] * f_w;
   __syncthreads();
 
-  // thread -> (q head qh, 8 consecutive d)
-  constexpr int TPH = D / 8;
-  const int qh = threadIdx.x / TPH, d0 = (threadIdx.x % TPH) * 8;
-  if (qh >= G || d0 >= dr) return;
-  float mt = -FLT_MAX;
+  // thread -> (q head qh, 8 consecutive d); head 256: 32 threads per q head, two passes over the 16 heads
+  constexpr int TPH = D / 8, HPP = NW * 64 / TPH;
+  const int d0 = (threadIdx.x % TPH) * 8;
+  if (d0 >= dr) return;
+  for (int qh = threadIdx.x / TPH; qh < G; qh += HPP) {
+    float mt = -FLT_MAX;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) mt = fmaxf(mt, ml[(w * 16 + qh) * 2]);
-  float lt = 0.f;
+    for (int w = 0; w < NW; ++w) mt = fmaxf(mt, ml[(w * 16 + qh) * 2]);
+    float lt = 0.f;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) lt += ml[(w * 16 + qh) * 2 + 1] * fast_exp2(ml[(w * 16 + qh) * 2] - mt);
-  float acc[8];
+    for (int w = 0; w < NW; ++w) lt += ml[(w * 16 + qh) * 2 + 1] * fast_exp2(ml[(w * 16 + qh) * 2] - mt);
+    float acc[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float a = 0.f;
+    for (int j = 0; j < 8; ++j) {
+      float a = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) a += om[(w * D + d0 + j) * 16 + qh];
-    acc[j] = a;
-  }
-  const int head = head0 + qh;
-  if (split) {
-    // unnormalised partial (v_scale applied), running max in the log2 domain, sum
-    const int64_t row = ((int64_t)qtok * p.num_heads + head) * p.segm_stride + seg;
-    float* so = p.segm_out + row * dr + d0;
-    *reinterpret_cast<f32x4*>(so) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
-    *reinterpret_cast<f32x4*>(so + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
-    if (d0 == 0) {
-      p.segm_max[row] = lt > 0.f ? mt : -INFINITY;
-      p.segm_sum[row] = lt;
+      for (int w = 0; w < NW; ++w) a += om[(w * D + d0 + j) * 16 + qh];
+      acc[j] = a;
     }
-    return;
-  }
-  const float inv = lt > 0.f ? 1.0f / lt : 0.f;   // acc / L (:276); nothing visible gives 0
-  if (p.out_scale) {
-    const float oi = inv * (1.0f / *p.out_scale);
-    uint8_t* op = (uint8_t*)p.out + (int64_t)qtok * p.o_stride_t + (int64_t)head * p.o_stride_h + d0;
-    *reinterpret_cast<uint2*>(op) =
-        make_uint2(f32x4_to_fp8x4(acc[0] * oi, acc[1] * oi, acc[2] * oi, acc[3] * oi),
-                   f32x4_to_fp8x4(acc[4] * oi, acc[5] * oi, acc[6] * oi, acc[7] * oi));
-  } else {
-    T* op = (T*)p.out + (int64_t)qtok * p.o_stride_t + (int64_t)head * p.o_stride_h + d0;
-    *reinterpret_cast<uint4*>(op) =
-        make_uint4(Mma<T>::pack2(acc[0] * inv, acc[1] * inv), Mma<T>::pack2(acc[2] * inv, acc[3] * inv),
-                   Mma<T>::pack2(acc[4] * inv, acc[5] * inv), Mma<T>::pack2(acc[6] * inv, acc[7] * inv));
+    const int head = head0 + qh;
+    if (split) {
+      // unnormalised partial (v_scale applied), running max in the log2 domain, sum
+      const int64_t row = ((int64_t)qtok * p.num_heads + head) * p.segm_stride + seg;
+      float* so = p.segm_out + row * dr + d0;
+      *reinterpret_cast<f32x4*>(so) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+      *reinterpret_cast<f32x4*>(so + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+      if (d0 == 0) {
+        p.segm_max[row] = lt > 0.f ? mt : -INFINITY;
+        p.segm_sum[row] = lt;
+      }
+      continue;
+    }
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;   // acc / L (:276); nothing visible gives 0
+    if (p.out_scale) {
+      const float oi = inv * (1.0f / *p.out_scale);
+      uint8_t* op = (uint8_t*)p.out + (int64_t)qtok * p.o_stride_t + (int64_t)head * p.o_stride_h + d0;
+      *reinterpret_cast<uint2*>(op) =
+          make_uint2(f32x4_to_fp8x4(acc[0] * oi, acc[1] * oi, acc[2] * oi, acc[3] * oi),
+                     f32x4_to_fp8x4(acc[4] * oi, acc[5] * oi, acc[6] * oi, acc[7] * oi));
+    } else {
+      T* op = (T*)p.out + (int64_t)qtok * p.o_stride_t + (int64_t)head * p.o_stride_h + d0;
+      *reinterpret_cast<uint4*>(op) =
+          make_uint4(Mma<T>::pack2(acc[0] * inv, acc[1] * inv), Mma<T>::pack2(acc[2] * inv, acc[3] * inv),
+                     Mma<T>::pack2(acc[4] * inv, acc[5] * inv), Mma<T>::pack2(acc[6] * inv, acc[7] * inv));
+    }
   }
 }
 
@@ -506,12 +509,12 @@ int launch(const UniDecodeParams& p) {
 }  // namespace
 
 bool unified_decode_supported(const UniDecodeParams& p) {
-  // head sizes up to 128 in whole 16-byte K chunks and 8-element output pieces (padded to 64 / 128)
-  if (p.head_size < 8 || p.head_size > 128 || p.head_size % (p.fp8 ? 16 : 8) != 0) return false;
+  // head sizes up to 256 in whole 16-byte K chunks and 8-element output pieces (padded to 64 / 128 / 256)
+  if (p.head_size < 8 || p.head_size > 256 || p.head_size % (p.fp8 ? 16 : 8) != 0) return false;
   if (p.block_size < 16 || (p.block_size & (p.block_size - 1)) != 0) return false;
   if (p.num_kv_heads <= 0 || p.num_heads % p.num_kv_heads != 0) return false;
   const int es = p.fp8 ? 1 : 2;
-  const int vrow = (p.head_size <= 64 ? 4 : 8) * es;   // bytes of a V row one lane loads (4, 8 or 16)
+  const int vrow = (p.head_size <= 64 ? 4 : p.head_size <= 128 ? 8 : 16) * es;   // bytes of a V row one lane loads (4 .. 32)
   if (p.vc_slot_bytes % vrow || p.vc_block_bytes % vrow || p.vc_head_bytes % vrow) return false;
   if (p.kc_slot_bytes % 16 || p.kc_block_bytes % 16 || p.kc_head_bytes % 16) return false;
   if (p.q_stride_t % 8 || p.q_stride_h % 8 || (((uintptr_t)p.q) & 15)) return false;
@@ -523,7 +526,8 @@ bool unified_decode_supported(const UniDecodeParams& p) {
 
 int unified_decode(const UniDecodeParams& p) {
 #define L(T) \
-  (p.head_size > 64 ? (p.fp8 ? launch<T, true, 128>(p) : launch<T, false, 128>(p)) \
+  (p.head_size > 128 ? (p.fp8 ? launch<T, true, 256>(p) : launch<T, false, 256>(p))  \
+   : p.head_size > 64 ? (p.fp8 ? launch<T, true, 128>(p) : launch<T, false, 128>(p)) \
                       : (p.fp8 ? launch<T, true, 64>(p) : launch<T, false, 64>(p)))
   return p.dtype == VLLM_AMD_F16 ? L(f16_t) : L(bf16_t);
 #undef L
