@@ -103,6 +103,39 @@ def test_reshape_and_cache_prefill_runs(ops, oracle, dtype, kv, D, BS, T):
     assert torch.equal(vc_d.cpu().view(torch.uint8), vc_o.view(torch.uint8))
 
 
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+@pytest.mark.parametrize("lens", [[1000, 777, 1333, 15, 1, 16, 17, 530], [31] * 40, [4100]])
+@pytest.mark.parametrize("first", [0, 5])
+def test_reshape_and_cache_batched_prompts(ops, oracle, kv, lens, first):
+    """A batch of prompts of odd lengths: every sequence starts at its own block (the first one `first` slots in, a
+    chunked-prefill continuation) but at a token index that is no multiple of 16 -- the run kernel's workgroups
+    follow the slots' 16-groups, whole groups inside a run, partial ones at its two ends."""
+    D, BS, H, dtype = 128, 16, 8, torch.bfloat16
+    T = sum(lens)
+    NB = sum((ln + first + BS - 1) // BS for ln in lens) + 3
+    g = torch.Generator().manual_seed(T + first)
+    blocks = torch.randperm(NB, generator=g).tolist()
+    slots, bi = [], 0
+    for si, ln in enumerate(lens):
+        for pos in range(first if si == 0 else 0, ln + (first if si == 0 else 0)):
+            slots.append(blocks[bi + pos // BS] * BS + pos % BS)
+        bi += (ln + first + BS - 1) // BS
+    slots = torch.tensor(slots, dtype=torch.int64)
+    key, value = _kv_inputs(T, H, D, dtype, T, strided=False)
+    x = x_of(dtype, kv)
+    cdt = dtype if kv == "auto" else torch.uint8
+    ks, vs = (0.05, 0.04) if kv != "auto" else (1.0, 1.0)
+    kc0 = torch.randint(0, 120, (NB, H, D // x, BS, x), generator=g).to(cdt)
+    vc0 = torch.randint(0, 120, (NB, H, D, BS), generator=g).to(cdt)
+    kc_o, vc_o = kc0.clone(), vc0.clone()
+    oracle.reshape_and_cache(key, value, kc_o, vc_o, slots, kv, ks, vs)
+    kc_d, vc_d = kc0.cuda(), vc0.cuda()
+    ops.reshape_and_cache(key.cuda(), value.cuda(), kc_d, vc_d, slots.cuda(), kv,
+                          torch.tensor([ks], device="cuda"), torch.tensor([vs], device="cuda"))
+    assert torch.equal(kc_d.cpu().view(torch.uint8), kc_o.view(torch.uint8))
+    assert torch.equal(vc_d.cpu().view(torch.uint8), vc_o.view(torch.uint8))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kv", ["auto", "fp8"])
 @pytest.mark.parametrize("layout", ["NHD", "HND"])
