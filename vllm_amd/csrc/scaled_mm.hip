@@ -306,7 +306,7 @@ static int launch_scaled_mm(void* out, const void* a, const void* b, const float
   // "mm_kernel" 11 forces it.
   const bool skinny = g_mm_kernel == 11 ||
                       (g_mm_kernel == 0 &&
-                       (!glds_ok || (M <= (K >= 12288 ? 8 : 16) && ceil_div(N, 16) <= 256)));
+                       (!glds_ok || (M <= 16 && ceil_div(N, 16) <= 256)));   // (round 3, HBM-served weights: 14336 x 4096 at M 16 18.9 vs 20.3 us)
   if (M <= 32 && skinny) {
     const int mt = ceil_div(M, 16);
 #define SK(T, MT)                                                                              \
