@@ -423,9 +423,10 @@ __device__ __forceinline__ void pa_piece(const PaK<scalar_t>& A, char* lds, cons
 
   // thread -> (q head qh, 8 consecutive d)
   constexpr int TPH = HEAD_SIZE / 8;             // threads per head row
-  const int qh = threadIdx.x / TPH;
+  constexpr int HPP = NW * 64 / TPH;             // head rows per pass (head 256: 8, two passes over 16 q heads)
+  const int qh0 = threadIdx.x / TPH;
   const int d0 = (threadIdx.x % TPH) * 8;
-  if (qh < nheads && (!PAD || d0 < dr)) {
+  for (int qh = qh0; qh < nheads; qh += HPP) if (!PAD || d0 < dr) {
     // l_tot / m_tot of column qh live in lanes with c16 == qh; recompute from LDS
     float mt = -FLT_MAX;
 #pragma unroll
@@ -490,7 +491,7 @@ __device__ __forceinline__ void pa_piece(const PaK<scalar_t>& A, char* lds, cons
   }
   __syncthreads();
   if (*flag == 0) return;
-  if (qh < nheads && (!PAD || d0 < dr)) {
+  for (int qh = qh0; qh < nheads; qh += HPP) if (!PAD || d0 < dr) {
     float M = -FLT_MAX, L = 0.f, acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -533,7 +534,7 @@ __device__ __forceinline__ void pa_piece(const PaK<scalar_t>& A, char* lds, cons
 }
 
 template <typename scalar_t, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int NW, int VARIANT, bool PAD, bool BAL>
-__global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
+__global__ __launch_bounds__(NW * 64, (HEAD_SIZE > 128 ? 1 : 2)) void pa_mfma_kernel(
     scalar_t* __restrict__ out, float* __restrict__ exp_sums, float* __restrict__ max_logits,
     const scalar_t* __restrict__ q, const uint8_t* __restrict__ k_cache,
     const uint8_t* __restrict__ v_cache, int num_heads, int num_kv_heads, float scale,
@@ -693,8 +694,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pa_mfma_kernel(
 // ------------------------------------------------------------------------------------
 bool paged_attention_mfma_supported(const PagedAttnParams& p) {
   if (p.dtype != VLLM_AMD_F16 && p.dtype != VLLM_AMD_BF16) return false;
-  // head sizes up to 128 in whole 16-byte chunks of K and of the output (padded to 64 / 128)
-  if (p.head_size < 16 || p.head_size > 128 ||
+  // head sizes up to 256 in whole 16-byte chunks of K and of the output (padded to 64 / 128 / 256)
+  if (p.head_size < 16 || p.head_size > 256 ||
       p.head_size % (p.kv_dtype == VLLM_AMD_KV_AUTO ? 8 : 16) != 0)
     return false;
   if (p.block_size != 16 && p.block_size != 32) return false;
@@ -792,6 +793,7 @@ static int launch_mfma_v(const PagedAttnParams& p) {
   // 5-7 us at the end of the launch, so it pays on skewed batches (one long sequence among many
   // short ones) and loses 2-7 us on uniform and mildly ragged ones -- the host cannot tell the
   // two apart (seq_lens live on the device), hence not the default.
+  if constexpr (HS <= 128)   // (head 256: one workgroup per CU, not instantiated)
   if (!part && !p.query_start_loc && p.window == 0 && g_pa_balance == 1) {
     const int groups = p.num_kv_heads * chunks;
     const int64_t steps_ub = (int64_t)p.num_seqs * ceil_div(p.max_seq_len > 0 ? p.max_seq_len : 1, FP8 ? 64 : 32);
@@ -835,12 +837,15 @@ static int launch_mfma(const PagedAttnParams& p) {
 template <typename scalar_t>
 static int dispatch_mfma(const PagedAttnParams& p) {
   const bool fp8 = p.kv_dtype == VLLM_AMD_KV_FP8_E4M3;
-  const int hs = p.head_size <= 64 ? 64 : 128;   // padded
+  const int hs = p.head_size <= 64 ? 64 : p.head_size <= 128 ? 128 : 256;   // padded
 #define L(HS, BS) return fp8 ? launch_mfma<scalar_t, true, HS, BS>(p) : launch_mfma<scalar_t, false, HS, BS>(p)
   if (hs == 128 && p.block_size == 16) L(128, 16);
   if (hs == 128 && p.block_size == 32) L(128, 32);
   if (hs == 64 && p.block_size == 16) L(64, 16);
   if (hs == 64 && p.block_size == 32) L(64, 32);
+  // head sizes 136 .. 256 (the reference's 192 and 256): the registers of a step double, one workgroup per CU
+  if (hs == 256 && p.block_size == 16) L(256, 16);
+  if (hs == 256 && p.block_size == 32) L(256, 32);
 #undef L
   VA_REQUIRE(false, VLLM_AMD_EUNSUPPORTED, "paged_attention mfma: unsupported shape");
 }
