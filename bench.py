@@ -501,6 +501,47 @@ def run_unified_decode(device, iters=5):
     return out
 
 
+def run_wide_heads(device, iters=5):
+    """Head size 256 (the reference's largest: Gemma-class models) through the three attention ops, fp8 cache,
+    16 q / 8 kv heads: V0 decode (x layout), V1 decode (flash layout, head-major memory) and a V1 prefill chunk."""
+    from vllm_amd.attention.ops import unified_attention
+    H, KVH, D, BS = 16, 8, 256, 16
+    out = {}
+    r = run_attention_shape("head 256", 64, 4096, H, KVH, device, D=D)
+    out["paged_attention_S64_ctx4096_fp8kv"] = {k: r[k] for k in ("us", "gbps_total", "frac_of_hbm_peak")}
+    sc = torch.full((1,), 0.02, device=device)
+    S, ctx = 64, 4096
+    nb = ctx // BS
+    q = (torch.rand((S, H, D), device=device) - 0.5).to(torch.bfloat16)
+    o = torch.empty_like(q)
+    kf = torch.randint(0, 120, (S * nb, KVH, BS, D), device=device, dtype=torch.uint8).permute(0, 2, 1, 3)
+    vf = torch.randint(0, 120, (S * nb, KVH, BS, D), device=device, dtype=torch.uint8).permute(0, 2, 1, 3)
+    bt = torch.randperm(S * nb, device=device).to(torch.int32).view(S, nb)
+    cu = torch.arange(S + 1, device=device, dtype=torch.int32)
+    sl = torch.full((S,), ctx, dtype=torch.int32, device=device)
+    t = time_gpu_graph(lambda: unified_attention(q, kf, vf, o, cu, 1, sl, ctx, D ** -0.5, True, (-1, -1), bt,
+                                                 0.0, None, sc, sc), iters)
+    nbytes = 2 * S * ctx * KVH * D + 2 * S * H * D * 2 + S * nb * 4
+    out["unified_decode_S64_ctx4096_fp8kv_hnd"] = dict(us=round(t * 1e6, 1), gbps=round(nbytes / t / 1e9, 1),
+                                                       frac_of_hbm_peak=round(nbytes / t / 1e9 / HBM_PEAK_GBPS, 4))
+    del kf, vf
+    B, ql = 1, 8192
+    nbu = ql // BS
+    q = (torch.rand((ql, H, D), device=device) - 0.5).to(torch.bfloat16)
+    o = torch.empty_like(q)
+    kf = torch.randint(0, 120, (nbu, BS, KVH, D), device=device, dtype=torch.uint8)
+    vf = torch.randint(0, 120, (nbu, BS, KVH, D), device=device, dtype=torch.uint8)
+    bt = torch.randperm(nbu, device=device).to(torch.int32).view(1, nbu)
+    start = torch.tensor([0, ql], device=device, dtype=torch.int32)
+    seql = torch.tensor([ql], device=device, dtype=torch.int32)
+    t = time_gpu_graph(lambda: unified_attention(q, kf, vf, o, start, ql, seql, ql, D ** -0.5, True, (-1, -1), bt,
+                                                 0.0, None, sc, sc), iters)
+    flops = 4.0 * D * H * ql * (ql + 1) / 2
+    out["unified_prefill_B1_q8192_fp8kv"] = dict(us=round(t * 1e6, 1), tflops=round(flops / t / 1e12, 1),
+                                                 frac_of_bf16_peak=round(flops / t / 2.5e15, 4))
+    return out
+
+
 def cpu_baseline():
     """Reference CPU paged_attention_v1 on BASELINE.json configs[0] (32 seqs, ctx 1024,
     32q/8kv, d 128, block 16, bf16 KV), all host cores available to this process."""
@@ -806,6 +847,7 @@ def main():
             extra["fused_neighbours"] = run_fused_neighbours(device)
             extra["prefill_attention"] = run_prefill(device)
             extra["unified_decode"] = run_unified_decode(device)
+            extra["head_256"] = run_wide_heads(device)
             # the single-GPU shapes of configs[3] / configs[4] and a ragged configs[1] batch
             extra["configs3_per_gpu"] = run_attention_shape("configs[3] per-GPU", 256, 32768, 8, 1, device)
             extra["configs4_n1"] = run_attention_shape("configs[4] at N=1", 8, 131072, 64, 8, device)

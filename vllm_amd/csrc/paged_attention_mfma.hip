@@ -867,14 +867,15 @@ int paged_attention_mfma(const PagedAttnParams& p0) {
     // finish; the host does not know the batch's lengths (seq_lens live on the device).
     const int64_t base = (int64_t)p.num_seqs * p.num_kv_heads * chunks;
     const int64_t P = p.max_num_partitions;
+    const int64_t slots = p.head_size > 128 ? 256 : 512;   // head sizes above 128: one workgroup per CU
     int64_t sp;
-    if (base < 512) {
+    if (base < slots) {
       // Fewer (sequence, head) pairs than workgroup slots: the sequences must be cut to fill the
       // chip, and real batches are ragged, so aim at ~2048 workgroups of >= 2048 tokens -- the
       // hardware hands them out as others finish (ragged 16 x U[8k, 64k] tokens: 215 us, against
       // 239 us with the 512 longest pieces that a uniform batch would like best).
       const int64_t total = base * P;
-      const int64_t sp_fill = (total + 511) / 512, sp_bal = (total + 2047) / 2048;
+      const int64_t sp_fill = (total + slots - 1) / slots, sp_bal = (total + 4 * slots - 1) / (4 * slots);
       const int64_t sp_min = p.partition_size >= 2048 ? 1 : 2048 / p.partition_size;
       sp = sp_fill < sp_min ? sp_fill : sp_min;
       if (sp < sp_bal) sp = sp_bal;
@@ -890,7 +891,7 @@ int paged_attention_mfma(const PagedAttnParams& p0) {
       sp = P;
       double best = 1e300;
       for (int64_t c = P; c >= 1 && c * p.partition_size >= 2048; --c) {
-        const int64_t pieces = (P + c - 1) / c, rounds = (base * pieces + 511) / 512;
+        const int64_t pieces = (P + c - 1) / c, rounds = (base * pieces + slots - 1) / slots;
         const double cost = (double)rounds * (double)(c * p.partition_size + 256);
         if (cost < best * 0.97) { best = cost; sp = c; }
       }
