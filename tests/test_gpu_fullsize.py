@@ -23,8 +23,9 @@ CASES = [
     ("configs1", 64, 32, 8, 4096, [0, 37, 63]),
     ("configs3_per_gpu", 256, 8, 1, 32768, [0, 255]),
     ("configs4", 8, 64, 8, 131072, [5]),
+    ("head256", 64, 16, 8, 4096, [0, 41], 256),   # the reference's largest head size at the configs[1] batch
 ]
-D, BS = 128, 16
+D, BS = 128, 16   # (D: the head size of the running case, set by test_fullsize_decode)
 
 
 def build(S, H, KVH, ctx, seed, ragged=False):
@@ -85,6 +86,15 @@ def oracle_rows(oracle, c, seqs):
 @pytest.mark.parametrize("ragged", [False, True])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_fullsize_decode(ops, oracle, case, ragged):
+    global D
+    D = case[6] if len(case) > 6 else 128
+    try:
+        _fullsize_decode(ops, oracle, case[:6], ragged)
+    finally:
+        D = 128
+
+
+def _fullsize_decode(ops, oracle, case, ragged):
     name, S, H, KVH, ctx, sample = case
     c = build(S, H, KVH, ctx, seed=len(name) + ragged, ragged=ragged)
     out = decode(c)
