@@ -84,8 +84,8 @@ class TritonAttentionBackend:
 
     @classmethod
     def get_supported_head_sizes(cls) -> list[int]:
-        # :147-148.  Up to 128: the MFMA tile / decode kernels; 160 .. 256: the wide-head kernel
-        # (unified_attention only: the prefill + paged-decode path stops at 128)
+        # :147-148.  Every size runs on the matrix-core prefill kernels and the bandwidth decode kernels
+        # (the prefill + paged-decode path: the paged-attention op's sizes only, i.e. not 160 / 224)
         return [32, 64, 96, 128, 160, 192, 224, 256]
 
     @classmethod
@@ -166,13 +166,13 @@ class TritonAttentionImpl:
         # envs.VLLM_V1_USE_PREFILL_DECODE_ATTENTION (vllm/envs.py)
         self.force_prefill_decode_attn = os.environ.get(
             "VLLM_V1_USE_PREFILL_DECODE_ATTENTION", "0").lower() in ("1", "true")
-        # chunked_prefill_paged_decode (context_attention_fwd + paged_attention_rocm) stops at head size 128;
-        # the wider heads only exist in unified_attention (functional coverage, a plain VALU kernel)
-        if self.force_prefill_decode_attn and head_size > 128:
+        # chunked_prefill_paged_decode = context_attention_fwd + the paged-attention op, which takes the reference's
+        # list of head sizes (csrc/attention/paged_attention_v1.cu:158-187: no 160, no 224)
+        pd_sizes = [h for h in TritonAttentionBackend.get_supported_head_sizes() if h not in (160, 224)]
+        if self.force_prefill_decode_attn and head_size not in pd_sizes:
             raise ValueError(
                 f"Head size {head_size} is not supported by TritonAttentionBackend with "
-                "VLLM_V1_USE_PREFILL_DECODE_ATTENTION=1. Supported head sizes there are: "
-                f"{[h for h in TritonAttentionBackend.get_supported_head_sizes() if h <= 128]}.")
+                f"VLLM_V1_USE_PREFILL_DECODE_ATTENTION=1. Supported head sizes there are: {pd_sizes}.")
 
     def forward(self, layer: torch.nn.Module, query: torch.Tensor, key: torch.Tensor,
                 value: torch.Tensor, kv_cache: torch.Tensor, attn_metadata,
