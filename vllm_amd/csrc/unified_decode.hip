@@ -511,6 +511,8 @@ int launch(const UniDecodeParams& p) {
 bool unified_decode_supported(const UniDecodeParams& p) {
   // head sizes up to 256 in whole 16-byte K chunks and 8-element output pieces (padded to 64 / 128 / 256)
   if (p.head_size < 8 || p.head_size > 256 || p.head_size % (p.fp8 ? 16 : 8) != 0) return false;
+  // the 256-wide form's lanes own 16 consecutive d of a V row: whole lanes only (136, 152 .. stay with the tile kernel)
+  if (p.head_size > 128 && p.head_size % 16 != 0) return false;
   if (p.block_size < 16 || (p.block_size & (p.block_size - 1)) != 0) return false;
   if (p.num_kv_heads <= 0 || p.num_heads % p.num_kv_heads != 0) return false;
   const int es = p.fp8 ? 1 : 2;
