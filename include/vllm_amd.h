@@ -493,6 +493,9 @@ int vllm_amd_ar_free_shared(void* ptr);
 /*                 64 / 128); 1 = unified_attention without GQA packing          */
 /*   "uni_decode": 0 = unified_attention never uses its decode kernel (1 =     */
 /*                 default; 2 / 3 = XCD-grouped workgroup order always / never) */
+/*   "uni_hp":     adjacent kv heads of a token-major cache taken as one row of  */
+/*                 that decode kernel (0 = heuristic, 1 = never, 2 / 4 = that    */
+/*                 many where the shape allows)                                  */
 /*   "pf_fa":      the 256-row kernel of unified_attention /                   */
 /*                 context_attention_fwd (prefill_fa.hip; head sizes 72 .. 256, */
 /*                 causal mask, unified: + sliding window, softcap): 0 = for launches whose longest query chunk fills */

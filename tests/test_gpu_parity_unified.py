@@ -193,6 +193,29 @@ def test_unified_decode_head_sizes(oracle, D, fp8, nseq):
         run(oracle, c, torch.bfloat16, fp8=fp8, window=90)
 
 
+@pytest.mark.parametrize("D_heads", [(128, (8, 4)), (64, (16, 8)), (64, (8, 4)), (32, (8, 8)), (128, (16, 2)), (64, (32, 4))])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("hp", [1, 2, 4])
+@pytest.mark.parametrize("mode", ["plain", "alibi", "window", "fp8_out"])
+@pytest.mark.parametrize("nseq", [5, 150])
+def test_unified_decode_packed_kv_heads(oracle, D_heads, fp8, hp, mode, nseq):
+    """Token-major caches: "uni_hp" adjacent kv heads are taken as one row of the decode kernel (their q heads are the
+    columns of one Q^T operand, zero outside the own head's d range; 1 = never, 2 / 4 = that many where the shape allows,
+    else fewer) -- split (5 sequences) and unsplit launches, every per-column feature, against the oracle."""
+    from vllm_amd import _lib
+    D, (H, KVH) = D_heads
+    lens = [3, 64, 65, 300, 1000]
+    seqs = [(1, lens[i % 5] + i // 5) for i in range(nseq)]
+    c = make_unified_case(seqs, H, KVH, D, 16, torch.bfloat16, fp8=fp8, seed=D + H + nseq, kv_scale=0.5)
+    slopes = 2.0 ** -(torch.arange(H).float() * 0.25 + 1) if mode == "alibi" else None
+    _lib.set_tuning("uni_hp", hp)
+    try:
+        run(oracle, c, torch.bfloat16, fp8=fp8, alibi=slopes, window=90 if mode == "window" else None,
+            out_scale=torch.tensor([0.02]) if mode == "fp8_out" else None)
+    finally:
+        _lib.set_tuning("uni_hp", 0)
+
+
 @pytest.mark.parametrize("heads", [(32, 1), (48, 2), (20, 1), (17, 1)])
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("nseq", [4, 600])

@@ -32,6 +32,7 @@ extern int g_mm_store;
 extern int g_mm_prio;
 extern int g_cache_runs;
 extern int g_cache_hpw;
+extern int g_uni_hp;
 extern int g_pf_rows;   // prefill_attention.hip
 extern int g_uni_decode;
 extern int g_pf_fa;
@@ -576,6 +577,7 @@ extern "C" int vllm_amd_set_tuning(const char* key, int value) {
   if (strcmp(key, "mm_kernel") == 0) { g_mm_kernel = value; return VLLM_AMD_OK; }
   if (strcmp(key, "cache_runs") == 0) { g_cache_runs = value; return VLLM_AMD_OK; }
   if (strcmp(key, "cache_hpw") == 0) { g_cache_hpw = value; return VLLM_AMD_OK; }
+  if (strcmp(key, "uni_hp") == 0) { g_uni_hp = value; return VLLM_AMD_OK; }
   if (strcmp(key, "mm_splitk") == 0) { g_mm_splitk = value; return VLLM_AMD_OK; }
   if (strcmp(key, "mm_tail") == 0) { g_mm_tail = value; return VLLM_AMD_OK; }
   if (strcmp(key, "mm_patch") == 0) { g_mm_patch = value; return VLLM_AMD_OK; }

@@ -788,14 +788,15 @@ static int launch_unified(PrefillParams p, int head_size, int block_size, int ma
     // workgroup pays ~4 us of prologue and merge next to ~25 ns per token of streaming: take the
     // smallest segment count within 5 % of the best estimate (513..1023 workgroups: ~1.3
     // rounds instead of 2); few sequences: as many segments of >= 256 tokens as allowed.
+    u.hp = unified_decode_heads_per_row(u);
     int nseg = 1;
     if (p.num_segments > 1 && !mixed) {
-      const int wgs = batch * p.num_kv_heads * ((gqa + 15) / 16);
+      const int wgs = batch * (p.num_kv_heads / u.hp) * ((gqa * u.hp + 15) / 16);
       int cap = (max_k + 4 * PF_BN - 1) / (4 * PF_BN);
       if (cap > p.num_segments) cap = p.num_segments;
       if (cap > 16) cap = 16;
       const float ovh = 160.f / (float)(max_k > 0 ? max_k : 1);
-      const int slots = head_size > 128 ? 256 : 512;   // head sizes above 128: one workgroup per CU (registers)
+      const int slots = head_size * u.hp > 128 ? 256 : 512;   // rows above 128 elements: one workgroup per CU (registers)
       auto cost = [&](int n) { return (float)((wgs * n + slots - 1) / slots) / n * (1.f + n * ovh); };
       float best = 1e30f;
       for (int n = 1; n <= cap; ++n) best = cost(n) < best ? cost(n) : best;

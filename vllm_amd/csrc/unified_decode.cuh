@@ -22,6 +22,7 @@ struct UniDecodeParams {
   int dtype;             // VLLM_AMD_F16 / VLLM_AMD_BF16
   bool fp8;              // e4m3 cache
   hipStream_t stream;
+  int hp = 1;            // adjacent kv heads taken as one row (unified_decode_heads_per_row: 1, 2 or 4)
 };
 
 bool pa_order_enabled();   // tuning "pa_order" (paged_attention_mfma.hip)
@@ -29,6 +30,8 @@ bool pa_order_enabled();   // tuning "pa_order" (paged_attention_mfma.hip)
 // true when every query of the launch may take the decode kernel (the caller has checked
 // max_seqlen_q == 1); false WITHOUT touching memory otherwise
 bool unified_decode_supported(const UniDecodeParams& p);
+// how many adjacent kv heads a workgroup row may take (1 = none): set UniDecodeParams::hp to it before unified_decode
+int unified_decode_heads_per_row(const UniDecodeParams& p);
 // main kernel and, with num_segments > 1 (at most 16), the merge of the segment partials
 int unified_decode(const UniDecodeParams& p);
 

@@ -80,26 +80,34 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void ua_decode_kernel(c
   }
   // GQA groups of more than 16 q heads (MQA models) take ceil(G / 16) workgroups per kv head,
   // chunk fastest: the chunks re-read the same K / V, through L2 when they run together
-  const int Gall = p.num_heads / p.num_kv_heads;
+  // hp > 1 (round 3, token-major caches): hp ADJACENT kv heads are taken as one row of hp * head_size elements -- one
+  // load instruction then fetches 256 contiguous bytes per token instead of 128 (or 64): pieces below 256 bytes cost
+  // 10 (128 B) to 40 % (64 B) of the bandwidth, 256-byte pieces nothing (tools/bench_uni_decode_d.py).  The q heads of
+  // the hp groups are the columns of ONE Q^T operand, each zero outside its own head's d range, so S^T, the per-column
+  // softmax and O^T come out per head with no other change; a column's output is its head's slice of the d rows.
+  const int hp = p.hp;
+  const int Gq = p.num_heads / p.num_kv_heads;   // q heads per kv head
+  const int nkv = p.num_kv_heads / hp;
+  const int Gall = Gq * hp;                      // (hp > 1: at most 16)
   const int chunks = (Gall + 15) >> 4;
   // unsplit launches of 257 .. 1024 workgroups: sequences handed out longest first, the two
   // workgroups of a CU paired long + short (pa_lpt_wg, common.cuh; same output bits)
   int lpt_len = -1;
   if (order > 0) {
-    const int groups = chunks * p.num_kv_heads;
+    const int groups = chunks * nkv;
     const bool xg = xcd_group != 0;
     wg = p.num_seqs <= 64    ? pa_lpt_wg<1>(p.seq_lens, p.num_seqs, groups, order, lane, wg, lpt_len, xg)
          : p.num_seqs <= 256 ? pa_lpt_wg<4>(p.seq_lens, p.num_seqs, groups, order, lane, wg, lpt_len, xg)
          : p.num_seqs <= 512 ? pa_lpt_wg<8>(p.seq_lens, p.num_seqs, groups, order, lane, wg, lpt_len, xg)
                              : pa_lpt_wg<16>(p.seq_lens, p.num_seqs, groups, order, lane, wg, lpt_len, xg);
   }
-  const int chunk = wg % chunks, kvh = (wg / chunks) % p.num_kv_heads, seq = wg / (chunks * p.num_kv_heads);
+  const int chunk = wg % chunks, kvh = (wg / chunks) % nkv, seq = wg / (chunks * nkv);
   const int seg = blockIdx.y;
   const int G = min(16, Gall - 16 * chunk);   // q heads of this workgroup
   const int head0 = kvh * Gall + 16 * chunk;
   // D = head size padded to 64 / 128 / 256: chunks at d >= dr are never loaded (zeros: no contribution to
   // the scores, output columns that are never stored)
-  const int dr = p.head_size;
+  const int dsub = p.head_size, dr = dsub * hp;
 
   // (all three loads before the first branch: one memory round trip, not two)
   const int seq_len = order > 0 ? lpt_len : p.seq_lens[seq];
@@ -141,13 +149,14 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void ua_decode_kernel(c
   // fp8 : K load i gives d = 16 (g4 + 4 i) + [0,16) -> two k-steps (lo / hi 8); 16 bit: d = 8 (g4 + 4 i) + [0,8)
   uint4 qf[QF];
   {
-    const T* qp = (const T*)p.q + (int64_t)qtok * p.q_stride_t + (int64_t)(head0 + c16) * p.q_stride_h;
+    const int dlo = hp > 1 ? (c16 / Gq) * dsub : 0;   // the column's head starts at row d = dlo
+    const T* qp = (const T*)p.q + (int64_t)qtok * p.q_stride_t + (int64_t)(head0 + c16) * p.q_stride_h - dlo;
 #pragma unroll
     for (int s = 0; s < QF; ++s) {
       int d;
       if constexpr (FP8) d = 16 * (g4 + 4 * (s >> 1)) + 8 * (s & 1);
       else d = 8 * (g4 + 4 * s);
-      qf[s] = (col_ok && d < dr) ? *reinterpret_cast<const uint4*>(qp + d) : make_uint4(0, 0, 0, 0);
+      qf[s] = (col_ok && d >= dlo && d < dlo + dsub) ? *reinterpret_cast<const uint4*>(qp + d) : make_uint4(0, 0, 0, 0);
     }
   }
 
@@ -181,8 +190,8 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void ua_decode_kernel(c
 #pragma unroll
   for (int r = 0; r < 4; ++r) voff[r] = (uint32_t)((4 * g4 + r) * p.vc_slot_bytes + c16 * (DT * ES));
   const bool vval = c16 * DT < dr;   // this lane's d elements exist
-  const uint8_t* const k_head = p.k_cache + (int64_t)kvh * p.kc_head_bytes;
-  const uint8_t* const v_head = p.v_cache + (int64_t)kvh * p.vc_head_bytes;
+  const uint8_t* const k_head = p.k_cache + (int64_t)kvh * hp * p.kc_head_bytes;
+  const uint8_t* const v_head = p.v_cache + (int64_t)kvh * hp * p.vc_head_bytes;
 
   auto load_pb = [&](int step) {
     if (step >= nsteps) return;
@@ -377,6 +386,8 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void ua_decode_kernel(c
   const int d0 = (threadIdx.x % TPH) * 8;
   if (d0 >= dr) return;
   for (int qh = threadIdx.x / TPH; qh < G; qh += HPP) {
+    const int dlo = hp > 1 ? (qh / Gq) * dsub : 0;   // this column's head: rows [dlo, dlo + dsub)
+    if (d0 < dlo || d0 >= dlo + dsub) continue;
     float mt = -FLT_MAX;
 #pragma unroll
     for (int w = 0; w < NW; ++w) mt = fmaxf(mt, ml[(w * 16 + qh) * 2]);
@@ -395,10 +406,10 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void ua_decode_kernel(c
     if (split) {
       // unnormalised partial (v_scale applied), running max in the log2 domain, sum
       const int64_t row = ((int64_t)qtok * p.num_heads + head) * p.segm_stride + seg;
-      float* so = p.segm_out + row * dr + d0;
+      float* so = p.segm_out + row * dsub + (d0 - dlo);
       *reinterpret_cast<f32x4*>(so) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
       *reinterpret_cast<f32x4*>(so + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
-      if (d0 == 0) {
+      if (d0 == dlo) {
         p.segm_max[row] = lt > 0.f ? mt : -INFINITY;
         p.segm_sum[row] = lt;
       }
@@ -407,12 +418,12 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void ua_decode_kernel(c
     const float inv = lt > 0.f ? 1.0f / lt : 0.f;   // acc / L (:276); nothing visible gives 0
     if (p.out_scale) {
       const float oi = inv * (1.0f / *p.out_scale);
-      uint8_t* op = (uint8_t*)p.out + (int64_t)qtok * p.o_stride_t + (int64_t)head * p.o_stride_h + d0;
+      uint8_t* op = (uint8_t*)p.out + (int64_t)qtok * p.o_stride_t + (int64_t)head * p.o_stride_h + (d0 - dlo);
       *reinterpret_cast<uint2*>(op) =
           make_uint2(f32x4_to_fp8x4(acc[0] * oi, acc[1] * oi, acc[2] * oi, acc[3] * oi),
                      f32x4_to_fp8x4(acc[4] * oi, acc[5] * oi, acc[6] * oi, acc[7] * oi));
     } else {
-      T* op = (T*)p.out + (int64_t)qtok * p.o_stride_t + (int64_t)head * p.o_stride_h + d0;
+      T* op = (T*)p.out + (int64_t)qtok * p.o_stride_t + (int64_t)head * p.o_stride_h + (d0 - dlo);
       *reinterpret_cast<uint4*>(op) =
           make_uint4(Mma<T>::pack2(acc[0] * inv, acc[1] * inv), Mma<T>::pack2(acc[2] * inv, acc[3] * inv),
                      Mma<T>::pack2(acc[4] * inv, acc[5] * inv), Mma<T>::pack2(acc[6] * inv, acc[7] * inv));
@@ -484,8 +495,8 @@ int launch(const UniDecodeParams& p) {
   constexpr int NW = 4;
   int sub_shift = 0;
   while ((16 << sub_shift) < p.block_size) ++sub_shift;
-  const int chunks = (p.num_heads / p.num_kv_heads + 15) / 16;
-  const dim3 grid((unsigned)(p.num_seqs * p.num_kv_heads * chunks), (unsigned)(p.num_segments > 1 ? p.num_segments : 1));
+  const int chunks = (p.hp * (p.num_heads / p.num_kv_heads) + 15) / 16;
+  const dim3 grid((unsigned)(p.num_seqs * (p.num_kv_heads / p.hp) * chunks), (unsigned)(p.num_segments > 1 ? p.num_segments : 1));
   const int xcd_group = g_uni_decode == 2 ? 1 : g_uni_decode == 3 ? 0 : (grid.x * grid.y >= 1024 ? 1 : 0);
   int order = 0;   // key bits of the longest-first order; tuning "pa_order" = 0 turns it off
   if (pa_order_enabled() && grid.y == 1 && grid.x > 256 && p.num_seqs <= kLptMaxSeqs &&
@@ -526,10 +537,43 @@ bool unified_decode_supported(const UniDecodeParams& p) {
   return true;
 }
 
+int g_uni_hp = 0;   // tuning "uni_hp": 0 = heuristic, 1 = never pack kv heads, 2 / 4 = that many when possible
+
+// kv heads taken per workgroup row (see the kernel): token-major caches whose (token, head) rows are shorter than 256
+// bytes; the packed width must be one of the instantiations and the q heads of the packed groups fit the 16 columns
+int unified_decode_heads_per_row(const UniDecodeParams& p) {
+  if (g_uni_hp == 1 || p.num_kv_heads <= 0) return 1;
+  const int es = p.fp8 ? 1 : 2, gq = p.num_heads / p.num_kv_heads;
+  if (p.kc_head_bytes != (int64_t)p.head_size * es || p.vc_head_bytes != (int64_t)p.head_size * es) return 1;   // heads not adjacent
+  if (p.head_size * es >= 256) return 1;                                                                         // long enough
+  const int64_t wgs = (int64_t)p.num_seqs * p.num_kv_heads * ((gq + 15) / 16);   // unpacked workgroups
+  // rows of up to 128 elements first (largest packing), then the 256-wide form
+  for (int pass = 0; pass < 2; ++pass)
+  for (int hp = 4; hp >= 2; hp >>= 1) {
+    const int w = p.head_size * hp;
+    if ((w > 128) != (pass == 1)) continue;
+    if ((w != 64 && w != 128 && w != 256) || gq * hp > 16 || p.num_kv_heads % hp != 0) continue;
+    if (g_uni_hp > 1) { if (hp > g_uni_hp) continue; }
+    else {
+      // Measured (16q..8kv x 4096 tokens, fp8, tools/bench_uni_decode_d.py): rows of up to 128 elements keep two
+      // workgroups per CU and always gain -- head 64: 2 heads per row 92 -> 52 us at 64 sequences, 291 -> 180 at 256
+      // (4 heads per row, the 256-wide form: 59 / 184); the 256-wide form (head 128 x 2) has one workgroup per CU and
+      // half as many workgroups: 102 -> 91 us at 64 sequences, 194 -> 178 at 128, 355 -> 357 at 256, 32 -> 35 at 16.
+      if (w * es > 256) continue;
+      if (w > 128 && (wgs < 512 || wgs >= 2048)) continue;
+    }
+    const int vrow = (w <= 64 ? 4 : w <= 128 ? 8 : 16) * es;
+    if (p.vc_slot_bytes % vrow || p.vc_block_bytes % vrow || (p.vc_head_bytes * hp) % vrow) continue;
+    return hp;
+  }
+  return 1;
+}
+
 int unified_decode(const UniDecodeParams& p) {
+  const int w = p.head_size * p.hp;   // (hp from unified_decode_heads_per_row, or 1)
 #define L(T) \
-  (p.head_size > 128 ? (p.fp8 ? launch<T, true, 256>(p) : launch<T, false, 256>(p))  \
-   : p.head_size > 64 ? (p.fp8 ? launch<T, true, 128>(p) : launch<T, false, 128>(p)) \
+  (w > 128 ? (p.fp8 ? launch<T, true, 256>(p) : launch<T, false, 256>(p))  \
+   : w > 64 ? (p.fp8 ? launch<T, true, 128>(p) : launch<T, false, 128>(p)) \
                       : (p.fp8 ? launch<T, true, 64>(p) : launch<T, false, 64>(p)))
   return p.dtype == VLLM_AMD_F16 ? L(f16_t) : L(bf16_t);
 #undef L
