@@ -55,9 +55,9 @@ __device__ __forceinline__ typename DwVec<N>::type nt_load(const uint8_t* p) {
 }
 
 template <typename T, bool FP8, int D, int NW>
-__global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void ua_decode_kernel(const UniDecodeParams p, int sub_shift, int xcd_group, int order) {
+__global__ __launch_bounds__(NW * 64, ((D > 128 && !FP8) ? 1 : 2)) void ua_decode_kernel(const UniDecodeParams p, int sub_shift, int xcd_group, int order) {
   constexpr int ES = FP8 ? 1 : 2;             // cache element bytes
-  constexpr int TILES = FP8 ? 4 : 2;          // 16-token tiles per step
+  constexpr int TILES = (FP8 && D <= 128) ? 4 : 2;   // 16-token tiles per step (the 256-wide form: 32-token steps -- 223 registers, two workgroups per CU)
   constexpr int STEP_TOK = TILES * 16;
   constexpr int KS = TILES / 2;               // k-steps (tile pairs) of the PV product per step
   constexpr int DT = D / 16;                  // PV MFMAs per k-step = d elements a lane owns per token
@@ -546,7 +546,6 @@ int unified_decode_heads_per_row(const UniDecodeParams& p) {
   const int es = p.fp8 ? 1 : 2, gq = p.num_heads / p.num_kv_heads;
   if (p.kc_head_bytes != (int64_t)p.head_size * es || p.vc_head_bytes != (int64_t)p.head_size * es) return 1;   // heads not adjacent
   if (p.head_size * es >= 256) return 1;                                                                         // long enough
-  const int64_t wgs = (int64_t)p.num_seqs * p.num_kv_heads * ((gq + 15) / 16);   // unpacked workgroups
   // rows of up to 128 elements first (largest packing), then the 256-wide form
   for (int pass = 0; pass < 2; ++pass)
   for (int hp = 4; hp >= 2; hp >>= 1) {
@@ -555,12 +554,12 @@ int unified_decode_heads_per_row(const UniDecodeParams& p) {
     if ((w != 64 && w != 128 && w != 256) || gq * hp > 16 || p.num_kv_heads % hp != 0) continue;
     if (g_uni_hp > 1) { if (hp > g_uni_hp) continue; }
     else {
-      // Measured (16q..8kv x 4096 tokens, fp8, tools/bench_uni_decode_d.py): rows of up to 128 elements keep two
-      // workgroups per CU and always gain -- head 64: 2 heads per row 92 -> 52 us at 64 sequences, 291 -> 180 at 256
-      // (4 heads per row, the 256-wide form: 59 / 184); the 256-wide form (head 128 x 2) has one workgroup per CU and
-      // half as many workgroups: 102 -> 91 us at 64 sequences, 194 -> 178 at 128, 355 -> 357 at 256, 32 -> 35 at 16.
+      // Measured (16q / 8kv and 8q / 4kv x 4096 tokens, fp8, tools/bench_uni_decode_d.py): rows of up to 128 elements
+      // always gain -- head 64: 2 heads per row 92 -> 52 us at 64 sequences, 291 -> 180 at 256 (4 heads per row, the
+      // 256-wide form: 59 / 184); head 128 x 2 in the 256-wide form (fp8: 32-token steps, two workgroups per CU):
+      // 8 kv heads 102 -> 90 us at 64 sequences, 194 -> 171 at 128, 355 -> 353 at 256, 32.5 -> 32.1 at 16; 4 kv heads
+      // 92.8 -> 87.1 at 128, 180 -> 164.5 at 256.  (w * es <= 256: a 16-bit cache never reaches the 256-wide form here.)
       if (w * es > 256) continue;
-      if (w > 128 && (wgs < 512 || wgs >= 2048)) continue;
     }
     const int vrow = (w <= 64 ? 4 : w <= 128 ? 8 : 16) * es;
     if (p.vc_slot_bytes % vrow || p.vc_block_bytes % vrow || (p.vc_head_bytes * hp) % vrow) continue;
