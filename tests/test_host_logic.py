@@ -24,15 +24,18 @@ def test_kv_cache_shape_and_split():
     assert 120 in PagedAttention.get_supported_head_sizes()
 
 
-@pytest.mark.parametrize("S,H,max_len,want", [
-    (64, 32, 4096, "v1"),      # configs[1]: S*H = 2048 > 512
-    (8, 64, 131072, "v2"),     # configs[4]: > 8192
-    (4, 32, 300, "v1"),        # one partition
-    (4, 32, 2048, "v2"),       # S*H = 128 <= 512 and 4 partitions
-    (256, 8, 32768, "v2"),     # configs[3]
+@pytest.mark.parametrize("S,H,max_len,want,KVH", [
+    (64, 32, 4096, "v1", 8),      # configs[1]: S*H = 2048 > 512
+    (8, 64, 131072, "v2", 8),     # configs[4]: > 8192
+    (4, 32, 300, "v1", 8),        # one partition
+    (4, 32, 2048, "v2", 8),       # S*H = 128 <= 512 and 4 partitions
+    (256, 8, 32768, "v2", 8),     # configs[3]
+    (128, 8, 4096, "v2", 1),      # S*H = 1024 > 512, but 128 (sequence, kv head) workgroups: partitioned here
+    (256, 8, 2048, "v1", 1),      # 256 workgroups: one per CU
 ])
-def test_forward_decode_heuristic(monkeypatch, S, H, max_len, want):
-    """vllm/attention/ops/paged_attn.py:117-193: same choice and scratch shapes."""
+def test_forward_decode_heuristic(monkeypatch, S, H, max_len, want, KVH):
+    """vllm/attention/ops/paged_attn.py:117-193: same choice (refined where this implementation's workgroup count
+    differs from the reference's, see forward_decode) and scratch shapes."""
     from vllm_amd.attention import paged_attn
     calls = {}
     monkeypatch.setattr(paged_attn.ops, "paged_attention_v1",
@@ -45,7 +48,7 @@ def test_forward_decode_heuristic(monkeypatch, S, H, max_len, want):
     bt = torch.zeros((S, (max_len + 15) // 16), dtype=torch.int32)
     sl = torch.ones(S, dtype=torch.int32)
     one = torch.ones(1)
-    out = paged_attn.PagedAttention.forward_decode(q, kc, vc, bt, sl, max_len, "auto", 8, 0.1,
+    out = paged_attn.PagedAttention.forward_decode(q, kc, vc, bt, sl, max_len, "auto", KVH, 0.1,
                                                    None, one, one)
     assert out.shape == q.shape and list(calls) == [want]
     if want == "v2":

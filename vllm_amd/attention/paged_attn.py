@@ -67,9 +67,15 @@ class PagedAttention:
         block_size = value_cache.shape[3]
         num_seqs, num_heads, head_size = query.shape
         max_num_partitions = (max_seq_len + _PARTITION_SIZE - 1) // _PARTITION_SIZE
-        # reference heuristic, paged_attn.py:129-130
+        # reference heuristic, paged_attn.py:129-130 ...
         use_v1 = (max_seq_len <= 8192
                   and (max_num_partitions == 1 or num_seqs * num_heads > 512))
+        # ... refined for this implementation, whose decode kernel takes one workgroup per (sequence, kv head, 16 q heads of
+        # the group) where the reference's takes one per q head: below one workgroup per CU an unpartitioned launch leaves
+        # CUs idle (128 sequences x 4096 tokens, 8q / 1kv heads per GPU -- a TP-8 shard: 31.8 us as v1, 27 us partitioned)
+        if use_v1 and max_num_partitions > 1:
+            groups = num_kv_heads * ((num_heads // max(num_kv_heads, 1) + 15) // 16)
+            use_v1 = num_seqs * groups >= 256
         if use_v1:
             ops.paged_attention_v1(output, query, key_cache, value_cache, num_kv_heads, scale,
                                    block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
